@@ -1,0 +1,174 @@
+"""ctypes binding of the CPU oracle (oracle/liborbref.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, the smoke check and the cpu_baseline leg of bench.py import this module; the product
+package never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liborbref.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, f) for f in ("orb_ref.cpp", "orb_ref.h")]
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "liborbref.so"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
+        L.orbref_create.restype = vp
+        L.orbref_create.argtypes = [i32, f32, i32, i32, i32]
+        L.orbref_destroy.argtypes = [vp]
+        L.orbref_levels.argtypes = [vp]
+        L.orbref_scale_factor.restype = f32
+        L.orbref_scale_factor.argtypes = [vp]
+        L.orbref_table.argtypes = [vp, i32, vp]
+        L.orbref_extract.argtypes = [vp, vp, i32, i32, C.c_ssize_t, vp, vp, i32, vp]
+        L.orbref_level_size.argtypes = [vp, i32, vp, vp]
+        L.orbref_plane.argtypes = [vp, i32, i32, vp]
+        L.orbref_level_keypoints.argtypes = [vp, i32, vp, i32]
+        L.orbref_level_grid.argtypes = [vp, i32, vp]
+        L.orbref_level_candidates.argtypes = [vp, i32, vp, vp, i32]
+        L.orbref_level_retain.argtypes = [vp, i32, vp]
+        L.orbref_cvround.argtypes = [C.c_double]
+        L.orbref_fast_atan2.restype = f32
+        L.orbref_fast_atan2.argtypes = [f32, f32]
+        L.orbref_resize_linear.argtypes = [vp, i32, i32, C.c_ssize_t, vp, i32, i32, C.c_ssize_t]
+        L.orbref_reflect101.argtypes = [i32, i32]
+        L.orbref_fast.argtypes = [vp, i32, i32, C.c_ssize_t, i32, vp, i32]
+        L.orbref_fast_measure.argtypes = [vp, C.c_ssize_t]
+        L.orbref_retain_best.argtypes = [vp, i32, i32, vp]
+        L.orbref_nth_prefix.argtypes = [vp, i32, i32, vp]
+        L.orbref_gauss7.argtypes = [vp, i32, i32, vp]
+        L.orbref_ic_angle.restype = f32
+        L.orbref_ic_angle.argtypes = [vp, C.c_ssize_t]
+        L.orbref_descriptor.argtypes = [vp, C.c_ssize_t, f32, vp]
+        L.orbref_cosf.restype = f32
+        L.orbref_cosf.argtypes = [f32]
+        L.orbref_sinf.restype = f32
+        L.orbref_sinf.argtypes = [f32]
+        L.orbref_hamming.argtypes = [vp, vp]
+        L.orbref_knn2.argtypes = [vp, i32, vp, i32, vp, vp, vp]
+        L.orbref_knn2_indexed.argtypes = [vp, vp, vp, i32, vp, vp, vp]
+        L.orbref_ratio_accept.argtypes = [i32, i32, f32, i32]
+        L.orbref_three_maxima.argtypes = [vp, i32, vp]
+        L.orbref_rot_bin.argtypes = [f32, f32]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class RefExtractor:
+    """Mirror of ORB_SLAM::ORBextractor (include/ORBextractor.h:32-77) over the oracle."""
+    HARRIS_SCORE, FAST_SCORE = 0, 1
+
+    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, scoreType=1, fastTh=20):
+        self._h = lib().orbref_create(nfeatures, scaleFactor, nlevels, scoreType, fastTh)
+        if not self._h:
+            raise ValueError("bad extractor parameters")
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orbref_destroy(self._h)
+            self._h = None
+
+    def GetLevels(self):
+        return lib().orbref_levels(self._h)
+
+    def GetScaleFactor(self):
+        return lib().orbref_scale_factor(self._h)
+
+    def table(self, which):
+        dt = np.float32 if which in (1, 2) else np.int32
+        out = np.zeros(64, dtype=dt)
+        n = lib().orbref_table(self._h, which, _p(out))
+        return out[:n].copy()
+
+    def __call__(self, image):
+        """Returns (keypoints[N] structured, descriptors[N,32] u8)."""
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        rows, cols = image.shape if image.ndim == 2 else (0, 0)
+        cap = self.nfeatures
+        kp = np.zeros(cap, dtype=KP_DTYPE)
+        desc = np.zeros((cap, 32), dtype=np.uint8)
+        n = C.c_int(0)
+        rc = lib().orbref_extract(self._h, _p(image), rows, cols, image.strides[0] if image.ndim == 2 else 0,
+                                  _p(kp), _p(desc), cap, C.byref(n))
+        if rc != 0:
+            raise RuntimeError("orbref_extract failed (%d)" % rc)
+        return kp[:n.value].copy(), desc[:n.value].copy()
+
+    # ---- stage taps ----
+    def level_size(self, level):
+        w, h = C.c_int(), C.c_int()
+        lib().orbref_level_size(self._h, level, C.byref(w), C.byref(h))
+        return w.value, h.value
+
+    def plane(self, level, blurred=False):
+        w, h = self.level_size(level)
+        out = np.zeros((h + 32, w + 32), dtype=np.uint8)
+        n = lib().orbref_plane(self._h, level, int(blurred), _p(out))
+        return out if n else None
+
+    def level_keypoints(self, level):
+        out = np.zeros((self.nfeatures * 2 + 16, 3), dtype=np.int32)
+        n = lib().orbref_level_keypoints(self._h, level, _p(out), out.shape[0])
+        return out[:n].copy()
+
+    def level_grid(self, level):
+        out = np.zeros(5, dtype=np.int32)
+        lib().orbref_level_grid(self._h, level, _p(out))
+        return dict(cols=int(out[0]), rows=int(out[1]), cellW=int(out[2]), cellH=int(out[3]), nfeaturesCell=int(out[4]))
+
+    def level_candidates(self, level):
+        g = self.level_grid(level)
+        w, h = self.level_size(level)
+        counts = np.zeros(g["cols"] * g["rows"], dtype=np.int32)
+        cap = w * h // 4 + 64
+        xyr = np.zeros((cap, 3), dtype=np.int32)
+        n = lib().orbref_level_candidates(self._h, level, _p(counts), _p(xyr), cap)
+        return counts, xyr[:n].copy()
+
+    def level_retain(self, level):
+        g = self.level_grid(level)
+        out = np.zeros(g["cols"] * g["rows"], dtype=np.int32)
+        lib().orbref_level_retain(self._h, level, _p(out))
+        return out
+
+
+def hamming(a, b):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    b = np.ascontiguousarray(b, dtype=np.uint8)
+    return lib().orbref_hamming(_p(a), _p(b))
+
+
+def knn2(q, t):
+    q = np.ascontiguousarray(q, dtype=np.uint8).reshape(-1, 32)
+    t = np.ascontiguousarray(t, dtype=np.uint8).reshape(-1, 32)
+    nq, nt = q.shape[0], t.shape[0]
+    idx = np.zeros(nq, np.int32)
+    d1 = np.zeros(nq, np.int32)
+    d2 = np.zeros(nq, np.int32)
+    lib().orbref_knn2(_p(q), nq, _p(t), nt, _p(idx), _p(d1), _p(d2))
+    return idx, d1, d2

@@ -1,0 +1,67 @@
+"""Seeded synthetic inputs shared by the tests, the smoke check and bench.py.
+
+Images: filled axis-aligned rectangles and discs of random size 4..40 px and random grey on a
+black background, plus integer noise uniform[-6, 6].  The shapes give thousands of FAST corners
+per pyramid level with heavy score ties, which stresses the tie semantics of the per-cell and
+per-level keypoint selection.  Descriptors: uniform random 256-bit rows, a quarter of the
+queries being noisy copies of train rows and 5 % of the train rows exact duplicates, so that the
+best/second-best tie rule and the ratio test are exercised.
+"""
+import numpy as np
+
+
+def synth_image(width, height, frame_idx=0):
+    """One u8 grayscale frame, fully determined by (width, height, frame_idx)."""
+    rng = np.random.default_rng(seed=1000 + frame_idx)
+    img = np.zeros((height, width), dtype=np.int16)
+    area = width * height / 307200.0
+    n_rect = int(round(400 * area))
+    n_disc = int(round(200 * area))
+    rs = rng.integers(4, 41, size=(n_rect, 2))
+    rx = rng.integers(0, width, size=n_rect)
+    ry = rng.integers(0, height, size=n_rect)
+    rg = rng.integers(0, 256, size=n_rect)
+    ds = rng.integers(4, 41, size=n_disc)
+    dx = rng.integers(0, width, size=n_disc)
+    dy = rng.integers(0, height, size=n_disc)
+    dg = rng.integers(0, 256, size=n_disc)
+    for i in range(n_rect):
+        img[ry[i]:ry[i] + rs[i, 1], rx[i]:rx[i] + rs[i, 0]] = rg[i]
+    for i in range(n_disc):
+        r = ds[i] / 2.0
+        y0, y1 = max(0, int(dy[i] - r)), min(height, int(dy[i] + r) + 1)
+        x0, x1 = max(0, int(dx[i] - r)), min(width, int(dx[i] + r) + 1)
+        if y1 <= y0 or x1 <= x0:
+            continue
+        yy, xx = np.ogrid[y0:y1, x0:x1]
+        m = (yy - dy[i]) ** 2 + (xx - dx[i]) ** 2 <= r * r
+        img[y0:y1, x0:x1][m] = dg[i]
+    img += rng.integers(-6, 7, size=img.shape, dtype=np.int16)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def synth_batch(width, height, batch, first_idx=0):
+    return np.stack([synth_image(width, height, first_idx + i) for i in range(batch)])
+
+
+def synth_descriptors(nq, nt, seed=0):
+    """(queries[nq,32], train[nt,32]) u8 with planted near-duplicates and exact duplicates."""
+    rng = np.random.default_rng(seed)
+    train = rng.integers(0, 256, size=(nt, 32), dtype=np.uint8)
+    query = rng.integers(0, 256, size=(nq, 32), dtype=np.uint8)
+    if nt > 1:
+        ndup = max(1, nt // 20)
+        dst = rng.integers(0, nt, size=ndup)
+        src = rng.integers(0, nt, size=ndup)
+        train[dst] = train[src]
+    if nt > 0 and nq > 0:
+        ncopy = nq // 4
+        qi = rng.choice(nq, size=ncopy, replace=False)
+        ti = rng.integers(0, nt, size=ncopy)
+        query[qi] = train[ti]
+        nflip = rng.integers(0, 41, size=ncopy)
+        for k in range(ncopy):
+            bits = rng.integers(0, 256, size=nflip[k])
+            for b in bits:
+                query[qi[k], b >> 3] ^= np.uint8(1 << (b & 7))
+    return query, train
