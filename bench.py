@@ -1,0 +1,293 @@
+#!/usr/bin/env python3
+"""Benchmark of the ORB front end on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+
+One "step" is one pass of the extractor (pyramid, cell-grid FAST, selection, orientation, blur,
+rotated-BRIEF descriptors, keypoint records) over one batch of synthetic frames that is already
+resident in HBM.  The workload is the 1-GPU configuration of the headline metric: a batch of 256
+synthetic 1280x720 frames, 2000 features per frame.  With N > 1 (one process per GPU, launched by
+torch.distributed.run) every rank processes its own batch of 256 frames: frames are independent,
+so the path is sharded by frame batch with no data-path collective (weak scaling); the only
+collectives are the timing barrier and a MAX over ranks of the elapsed time.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      the dominant kernel group against HBM bandwidth (durations from HIP events on the
+                library's stream, collected in a separate profiled pass after the timed region)
+  cpu_baseline  the CPU oracle (oracle/, a port of the reference's CPU path) timed on the host
+                cores of this box on a bounded sample of the same frames
+  extra         the 640x480 / 1000-feature extraction rate and the Hamming kNN rate of the
+                same library, measured after the main timed region.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, spec
+
+
+def pyramid_pixels(ext, nlevels):
+    return sum(ext.level_geometry(l)["w"] * ext.level_geometry(l)["h"] for l in range(nlevels))
+
+
+def make_frames(synth, w, h, n, first):
+    return np.stack([synth.synth_image(w, h, first + i) for i in range(n)])
+
+
+class ExtractWorkload:
+    """Batch of frames resident in HBM + preallocated device outputs."""
+
+    def __init__(self, orb, torch, dev, w, h, nfeatures, batch, first_idx, frames=None):
+        self.torch = torch
+        self.w, self.h, self.nf, self.batch = w, h, nfeatures, batch
+        self.host = frames if frames is not None else make_frames(orb.synth, w, h, batch, first_idx)
+        self.ext = orb.ORBextractor(nfeatures, 1.2, 8, 1, 20, device=dev, max_width=w, max_height=h, max_batch=batch)
+        self.d_img = torch.from_numpy(self.host).to("cuda:%d" % dev)
+        self.d_kp = torch.zeros((batch, nfeatures, 7), dtype=torch.float32, device="cuda:%d" % dev)
+        self.d_desc = torch.zeros((batch, nfeatures, 32), dtype=torch.uint8, device="cuda:%d" % dev)
+        self.d_n = torch.zeros(batch, dtype=torch.int32, device="cuda:%d" % dev)
+        torch.cuda.synchronize(dev)
+
+    def step(self):
+        self.ext.extract_batch_device(self.d_img.data_ptr(), self.batch, self.h, self.w, self.w, self.w * self.h,
+                                      self.d_kp.data_ptr(), self.d_desc.data_ptr(), self.nf, self.d_n.data_ptr())
+
+    def sync(self):
+        self.ext.synchronize()
+
+
+def cpu_baseline(frames, nfeatures, threads, sample):
+    """Oracle (CPU port of the reference path) on `threads` host threads over `sample` frames."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orbref
+    from concurrent.futures import ThreadPoolExecutor
+    orbref.lib()
+    sample = min(sample, len(frames))
+    exts = [orbref.RefExtractor(nfeatures, 1.2, 8, 1, 20) for _ in range(threads)]
+    results = [None] * sample
+
+    def work(t):
+        for i in range(t, sample, threads):
+            results[i] = exts[t](frames[i])
+
+    exts[0](frames[0])  # touch code and pages once
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as pool:
+        list(pool.map(work, range(threads)))
+    dt = time.perf_counter() - t0
+    return sample / dt, results
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--features", type=int, default=2000)
+    ap.add_argument("--cpu-sample", type=int, default=96, help="frames of the CPU baseline sample")
+    ap.add_argument("--no-extra", action="store_true", help="skip the 640x480 and Hamming kNN legs")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if args.gpus != 1 and world == 1:
+            raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
+                             "--nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
+        args.gpus = world
+
+    orb = importlib.import_module("orb-slam2_amd")
+    orb._lib.lib()  # fails loudly if liborbhip.so is missing
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU")
+    dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    wl = ExtractWorkload(orb, torch, dev, args.width, args.height, args.features, args.batch, first_idx=rank * args.batch)
+
+    for _ in range(args.warmup):
+        wl.step()
+    wl.sync()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    wl.sync()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda:%d" % dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    frames_total = args.batch * args.steps * world
+    value = frames_total / elapsed
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel group: separate profiled pass ----------------------
+        nl = wl.ext.GetLevels()
+        P = pyramid_pixels(wl.ext, nl)
+        wl.ext.set_profiling(True)
+        prof_steps = max(3, min(args.steps, 10))
+        acc = {}
+        for _ in range(prof_steps):
+            wl.step()
+            wl.sync()
+            for s, (ms, n) in wl.ext.stage_times().items():
+                a = acc.setdefault(s, [0.0, 0])
+                a[0] += ms
+                a[1] += n
+        wl.ext.set_profiling(False)
+        n_kp = int(wl.d_n.sum().item())
+        # algorithmic bytes per frame of each kernel group: the 5 B/pixel + 60 B/keypoint of the
+        # whole path split by who must move them (pyramid: read + write; FAST: read; blur: read +
+        # write; outputs: 32 B descriptor + 28 B keypoint).
+        N_frame = n_kp / args.batch
+        lvl0 = args.width * args.height
+        alg = {"level0": 2 * lvl0, "resize": 2 * (P - lvl0), "fast_measure": P, "nms_compact": 0, "select": 0,
+               "orient": 0, "blur": 2 * P, "describe": 60 * N_frame}
+        stage_ms = {s: a[0] / prof_steps for s, a in acc.items()}
+        dominant = max(stage_ms, key=stage_ms.get)
+        launches = acc[dominant][1] // prof_steps
+        avg_launch_ms = stage_ms[dominant] / max(launches, 1)
+        bytes_per_launch = alg[dominant] * args.batch / max(launches, 1)
+        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        path_bytes = (5 * P + 60 * N_frame) * args.batch
+        path_ms = sum(stage_ms.values())
+        roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "launches_per_step": launches, "avg_launch_ms": round(avg_launch_ms, 5),
+                    "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                    "stage_ms_per_step": {s: round(v, 4) for s, v in stage_ms.items()},
+                    "whole_path": {"algorithmic_bytes_per_step": int(path_bytes), "kernel_ms_per_step": round(path_ms, 4),
+                                   "achieved": round(path_bytes / (path_ms * 1e-3) / 1e9, 2) if path_ms > 0 else 0.0,
+                                   "frac": round(path_bytes / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if path_ms > 0 else 0.0}}
+
+        # ---- CPU baseline on a bounded sample of the same frames + parity of that sample --------
+        threads = max(1, min(16, os.cpu_count() or 1))
+        cpu_fps, ref_results = cpu_baseline(wl.host, args.features, threads, args.cpu_sample)
+        kp = wl.d_kp.cpu().numpy().view(np.uint32)
+        desc = wl.d_desc.cpu().numpy()
+        ncount = wl.d_n.cpu().numpy()
+        mism = 0
+        for i, (rkp, rdesc) in enumerate(ref_results):
+            n = len(rkp)
+            same = ncount[i] == n and np.array_equal(kp[i, :n].reshape(-1), rkp.view(np.uint32).reshape(-1)) \
+                and np.array_equal(desc[i, :n], rdesc)
+            mism += 0 if same else 1
+        cpu = {"value": round(cpu_fps, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+               "sample": "%d of the %d frames of this workload (%dx%d, %d features), one oracle extractor per thread"
+                         % (len(ref_results), args.batch, args.width, args.height, args.features),
+               "parity_frames_checked": len(ref_results), "parity_frames_mismatching": mism}
+
+        extra = {}
+        if not args.no_extra:
+            extra = extra_legs(orb, torch, dev, threads)
+
+        out = {"metric": "orb_extract_frames_per_sec", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+               "config": {"workload": "batch of %d synthetic %dx%d frames per GPU, %d features/frame, 8 levels, scale 1.2, "
+                                      "full extract+describe" % (args.batch, args.width, args.height, args.features),
+                          "frames_per_gpu_per_step": args.batch, "keypoints_per_frame": round(N_frame, 1),
+                          "parallelism": "frame-batch sharding x%d, no data-path collective" % world},
+               "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
+    barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def extra_legs(orb, torch, dev, threads):
+    """640x480 / 1000-feature extraction rate and Hamming kNN rate (not the headline value)."""
+    res = {}
+    # extraction, 640x480, 1000 features, batch 256
+    b = 256
+    wl = ExtractWorkload(orb, torch, dev, 640, 480, 1000, b, first_idx=100000)
+    for _ in range(2):
+        wl.step()
+    wl.sync()
+    t0 = time.perf_counter()
+    k = 10
+    for _ in range(k):
+        wl.step()
+    wl.sync()
+    dt = time.perf_counter() - t0
+    fps = b * k / dt
+    cpu1, _ = cpu_baseline(wl.host, 1000, 1, 24)
+    cpuN, _ = cpu_baseline(wl.host, 1000, threads, 16 * threads)
+    res["extract_640x480_1000"] = {"frames_per_sec": round(fps, 1), "batch": b,
+                                   "cpu_oracle_1_thread_frames_per_sec": round(cpu1, 2),
+                                   "cpu_oracle_%d_threads_frames_per_sec" % threads: round(cpuN, 2),
+                                   "speedup_vs_1_thread": round(fps / cpu1, 1)}
+    del wl
+    # Hamming kNN k=2: pairs of 2000 x 2000 descriptors
+    m = orb.ORBmatcher(0.6, True, device=dev)
+    pairs, nq, nt = 1024, 2000, 2000
+    g = torch.Generator(device="cuda:%d" % dev)
+    g.manual_seed(1)
+    q = torch.randint(0, 256, (pairs, nq, 32), dtype=torch.uint8, device="cuda:%d" % dev, generator=g)
+    t = torch.randint(0, 256, (pairs, nt, 32), dtype=torch.uint8, device="cuda:%d" % dev, generator=g)
+    o = torch.zeros((3, pairs, nq), dtype=torch.int32, device="cuda:%d" % dev)
+    torch.cuda.synchronize(dev)
+
+    def run():
+        m.knn2_device(q.data_ptr(), nq, nq * 32, t.data_ptr(), nt, nt * 32, pairs, 0, o[0].data_ptr(), o[1].data_ptr(),
+                      o[2].data_ptr())
+
+    run()
+    m.synchronize()
+    ms = []
+    for _ in range(5):
+        run()
+        m.synchronize()
+        ms.append(m.last_elapsed_ms())
+    best = float(np.median(ms))
+    comps = pairs * nq * nt
+    rate = comps / (best * 1e-3)
+    peak_lane_ops = 256 * 4 * 32 * 2.4e9  # CUs x SIMDs x lanes/clk x clock = integer VALU lane-ops/s
+    # CPU: scalar scan of the oracle on one pair, one thread
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orbref
+    hq, ht = q[0].cpu().numpy(), t[0].cpu().numpy()
+    t0 = time.perf_counter()
+    ridx, rd1, rd2 = orbref.knn2(hq, ht)
+    cdt = time.perf_counter() - t0
+    oo = o[:, 0].cpu().numpy()
+    res["hamming_knn2"] = {"pairs": pairs, "nq": nq, "nt": nt, "comparisons_per_sec": float("%.4g" % rate),
+                           "ms": round(best, 4),
+                           "popcount_lane_ops_frac_of_valu_peak": round(rate * 8 / peak_lane_ops, 4),
+                           "valu_lane_ops_frac_of_peak": round(rate * 16 / peak_lane_ops, 4),
+                           "cpu_oracle_1_thread_comparisons_per_sec": float("%.4g" % (nq * nt / cdt)),
+                           "parity_pair0": bool(np.array_equal(oo[0], ridx) and np.array_equal(oo[1], rd1)
+                                                and np.array_equal(oo[2], rd2))}
+    return res
+
+
+if __name__ == "__main__":
+    main()

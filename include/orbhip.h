@@ -1,0 +1,169 @@
+/* orbhip — C ABI of the MI355X (gfx950) ORB front end.
+ *
+ * Drop-in boundary for the two classes of the reference that form its data-parallel hot path:
+ *   ORB_SLAM::ORBextractor  (include/ORBextractor.h:32-77, src/ORBextractor.cc)
+ *   ORB_SLAM::ORBmatcher::DescriptorDistance + the best/second-best scan every Search* method
+ *   runs (include/ORBmatcher.h:46, src/ORBmatcher.cc:461-487,1805-1821)
+ *
+ * Conventions: plain pointers and sizes, int status codes (0 = ok, < 0 = error), nothing throws
+ * across the boundary.  One call in flight per handle (the reference's extractor is not
+ * re-entrant either: include/ORBextractor.h:74-75 holds mutable pyramid scratch); stateless
+ * functions (orbhip_hamming_distance) are re-entrant.  All work of a handle is issued on the
+ * handle's own HIP stream; the *_device entry points are asynchronous on it.
+ */
+#ifndef ORBHIP_H
+#define ORBHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBHIP_OK 0
+#define ORBHIP_EINVAL (-1)   /* bad argument */
+#define ORBHIP_ENOMEM (-2)   /* device or host allocation failed */
+#define ORBHIP_EHIP (-3)     /* a HIP runtime call or kernel launch failed */
+#define ORBHIP_ECAP (-4)     /* caller's output capacity / handle's max size too small */
+#define ORBHIP_EGEOM (-5)    /* image too small for the cell grid the parameters imply */
+#define ORBHIP_ENODEV (-6)   /* no usable GPU */
+#define ORBHIP_EUNSUPPORTED (-7)
+
+#define ORBHIP_MAX_LEVELS 16
+#define ORBHIP_HARRIS_SCORE 0 /* include/ORBextractor.h:36 */
+#define ORBHIP_FAST_SCORE 1
+
+/* Field-for-field cv::KeyPoint of OpenCV 2.4 (28 bytes): what operator() fills
+ * (src/ORBextractor.cc:769-777). */
+typedef struct OrbKeypoint {
+    float x, y;      /* pt, level coordinates times mvScaleFactor[octave] */
+    float size;      /* (int)(31 * mvScaleFactor[octave]) */
+    float angle;     /* degrees in [0, 360) */
+    float response;  /* FAST score */
+    int32_t octave;
+    int32_t class_id; /* always -1 */
+} OrbKeypoint;
+
+typedef struct orbhip_extractor orbhip_extractor;
+
+/* Replaces ORBextractor::ORBextractor (include/ORBextractor.h:38, src/ORBextractor.cc:457-511).
+ * device: HIP device ordinal.  max_width/max_height/max_batch size the resident device arenas
+ * (pyramids of max_batch frames stay in HBM); larger batches are processed in chunks. */
+int orbhip_extractor_create(orbhip_extractor** out, int nfeatures, float scale_factor, int nlevels,
+                            int score_type, int fast_th, int device, int max_width, int max_height,
+                            int max_batch);
+void orbhip_extractor_destroy(orbhip_extractor* e);
+
+/* Replace ORBextractor::GetLevels / GetScaleFactor (include/ORBextractor.h:47-51). */
+int orbhip_levels(const orbhip_extractor* e);
+float orbhip_scale_factor(const orbhip_extractor* e);
+/* Constructor tables, for callers that mirror them (Frame recomputes scale factors from
+ * GetScaleFactor, src/Frame.cc:93-104).  which: 0 = features per level (int32[nlevels]),
+ * 1 = mvScaleFactor (float[nlevels]), 2 = mvInvScaleFactor (float[nlevels]).  Returns count. */
+int orbhip_table(const orbhip_extractor* e, int which, void* out);
+
+/* Replaces ORBextractor::operator() (include/ORBextractor.h:43-45, src/ORBextractor.cc:718-779)
+ * for one 8-bit single-channel image in host memory.  kp_out[cap], desc_out[cap*32] are host
+ * buffers, cap >= nfeatures.  The mask argument of the reference has no effect on its results
+ * (src/ORBextractor.cc:601-603 builds cellMask and never uses it) and is therefore not taken.
+ * rows == 0 || cols == 0 returns ORBHIP_OK without touching the outputs (:721-722).  Blocking. */
+int orbhip_extract(orbhip_extractor* e, const uint8_t* img, int rows, int cols, ptrdiff_t row_stride,
+                   OrbKeypoint* kp_out, uint8_t* desc_out, int cap, int* n_out);
+
+/* The same for a batch of equally sized frames in host memory (frame f starts at
+ * imgs + f * frame_stride).  Outputs are per frame at stride cap: kp_out[batch*cap],
+ * desc_out[batch*cap*32], n_out[batch].  Blocking. */
+int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int batch, int rows, int cols,
+                         ptrdiff_t row_stride, ptrdiff_t frame_stride, OrbKeypoint* kp_out,
+                         uint8_t* desc_out, int cap, int* n_out);
+
+/* The same with every buffer resident in device memory.  Asynchronous on the handle's stream:
+ * call orbhip_extractor_synchronize (or synchronise the device) before reading the outputs. */
+int orbhip_extract_batch_device(orbhip_extractor* e, const uint8_t* d_imgs, int batch, int rows,
+                                int cols, ptrdiff_t row_stride, ptrdiff_t frame_stride,
+                                OrbKeypoint* d_kp_out, uint8_t* d_desc_out, int cap, int* d_n_out);
+int orbhip_extractor_synchronize(orbhip_extractor* e);
+/* The handle's hipStream_t, for callers that order their own work after the extraction. */
+void* orbhip_extractor_stream(orbhip_extractor* e);
+
+/* Stage taps of the last chunk processed (test instrumentation; blocking copies to host).
+ * stage: 0 = unblurred padded plane of (frame, level)  -> u8 (h+32) x (w+32), tightly packed
+ *        1 = blurred padded plane
+ *        2 = FAST corner measure plane (same shape; only the interior is defined)
+ *        3 = per-cell candidate counts of the level -> int32[nCells]
+ *        4 = per-cell nToRetain of the level -> int32[nCells]
+ *        5 = level keypoints after selection -> int32 triples x, y, score; returns count
+ *        6 = per-cell candidates, cell-major raster order -> int32 triples x, y (cell coords), score
+ * Returns the number of bytes (stages 0-2) or elements written, or < 0. */
+int orbhip_debug_get(orbhip_extractor* e, int stage, int frame, int level, void* buf, size_t buf_bytes);
+/* Level geometry of the current image size: out[0]=w, [1]=h, [2]=levelCols, [3]=levelRows,
+ * [4]=cellW, [5]=cellH, [6]=nfeaturesCell, [7]=quota. */
+int orbhip_level_geometry(const orbhip_extractor* e, int level, int32_t* out8);
+/* Kernel time of the last extract call on this handle, measured with HIP events on the handle's
+ * stream (milliseconds, whole call). */
+float orbhip_last_elapsed_ms(orbhip_extractor* e);
+
+/* Per-stage kernel timing (bench instrumentation).  With profiling enabled every extract call
+ * brackets its kernel groups with HIP events on the handle's stream; after
+ * orbhip_extractor_synchronize, stage_times returns for the last call the summed duration (ms) and
+ * the launch count of each group: 0 level-0 border copy, 1 pyramid resize, 2 FAST corner measure,
+ * 3 per-cell NMS + compaction, 4 quota + retainBest selection, 5 orientation, 6 Gaussian blur,
+ * 7 descriptors + keypoint records.  Returns the number of groups (8). */
+int orbhip_extractor_set_profiling(orbhip_extractor* e, int enable);
+int orbhip_extractor_stage_times(orbhip_extractor* e, float* ms_out8, int* launches_out8);
+
+/* Replaces ORBmatcher::DescriptorDistance (include/ORBmatcher.h:46, src/ORBmatcher.cc:1805-1821):
+ * Hamming distance of two 32-byte descriptors in host memory.  A single pair is never worth a
+ * kernel launch, so this is host popcount; re-entrant and lock-free. */
+int orbhip_hamming_distance(const void* a, const void* b);
+
+typedef struct orbhip_matcher orbhip_matcher;
+int orbhip_matcher_create(orbhip_matcher** out, int device);
+void orbhip_matcher_destroy(orbhip_matcher* m);
+int orbhip_matcher_synchronize(orbhip_matcher* m);
+void* orbhip_matcher_stream(orbhip_matcher* m);
+
+/* Replaces the best / second-best scan of src/ORBmatcher.cc:461-485 run over the full train set
+ * (identity candidate list), for npairs independent (query set, train set) pairs:
+ * pair p has queries q + p*q_pair_stride (nq rows of 32 B) and train rows t + p*t_pair_stride.
+ * Outputs per pair and query: idx (first train index attaining the minimum, + idx_base),
+ * d1 (minimum distance), d2 (second order statistic with multiplicity).  nt == 0 gives
+ * idx = -1, d1 = d2 = INT_MAX; nt == 1 gives d2 = INT_MAX, as the reference's INT_MAX
+ * initialisation does.  Device pointers; asynchronous on the matcher's stream. */
+int orbhip_knn2_device(orbhip_matcher* m, const uint8_t* d_q, int nq, ptrdiff_t q_pair_stride,
+                       const uint8_t* d_t, int nt, ptrdiff_t t_pair_stride, int npairs, int idx_base,
+                       int32_t* d_idx, int32_t* d_d1, int32_t* d_d2);
+/* Host-pointer convenience form of the above (copies in and out; blocking). */
+int orbhip_knn2(orbhip_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int nt, int npairs,
+                int32_t* idx, int32_t* d1, int32_t* d2);
+/* Merge of per-shard results of index-contiguous train shards (shard g owns a contiguous index
+ * range that precedes shard g+1's): parts[g*3*nq ...] holds idx, d1, d2 arrays of shard g.
+ * Reproduces the serial ascending scan exactly.  Device pointers; asynchronous. */
+int orbhip_knn2_merge_device(orbhip_matcher* m, const int32_t* d_parts, int nshards, int nq,
+                             int32_t* d_idx, int32_t* d_d1, int32_t* d_d2);
+/* Acceptance predicates of src/ORBmatcher.cc evaluated per query on the device:
+ * form 0: (float)d1 < ratio*(float)d2 (:237,:665,:804), 1: d1 <= d2*ratio (:487,:596);
+ * accepted iff the ratio form holds and d1 <= th (TH_LOW 20 / TH_HIGH 100, :42-45).
+ * accept[i] = 1/0.  d2 == INT_MAX passes every ratio form. */
+int orbhip_ratio_test_device(orbhip_matcher* m, const int32_t* d_d1, const int32_t* d_d2, int n,
+                             float ratio, int form, int th, uint8_t* d_accept);
+float orbhip_matcher_last_elapsed_ms(orbhip_matcher* m);
+
+/* Device self-tests of the arithmetic helpers (test instrumentation, host pointers, blocking):
+ * which 0: n (y, x) float pairs -> n floats, the device's fastAtan2 in degrees
+ *       1: n float angles (radians) -> n (cos, sin) float pairs as the descriptor kernel computes them
+ *       2: n uint32 keys (score in bits 31..24), aux = nth -> the keys as the device's
+ *          nth_element leaves them
+ *       3: n 7x7 u8 patches -> n int32 FAST corner measures of the patch centres */
+int orbhip_selftest(int which, const void* in, int n, int aux, void* out);
+
+/* Library/device facts. */
+int orbhip_device_count(void);
+const char* orbhip_version(void);
+const char* orbhip_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

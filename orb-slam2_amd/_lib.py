@@ -1,0 +1,95 @@
+"""Loader and ctypes prototypes of liborbhip.so (the C ABI of include/orbhip.h).
+
+There is no CPU fallback: if the shared library is missing the import of the product classes
+fails with an ImportError that says how to build it.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liborbhip.so")
+
+OK, EINVAL, ENOMEM, EHIP, ECAP, EGEOM, ENODEV, EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7
+
+_lib = None
+
+
+class OrbhipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("orbhip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _preload_torch_hip_runtime():
+    """PyTorch's ROCm wheel bundles its own libamdhip64.so with the same SONAME as the system one.
+    Two HIP runtimes in one process do not both see the GPU, so when torch is installed its copy
+    is loaded first (without importing torch) and liborbhip.so binds to it; torch then reuses it."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not found: build it with `make -C %s` (hipcc, gfx950); there is no CPU fallback"
+                          % (LIB_PATH, os.path.join(_HERE, "csrc")))
+    _preload_torch_hip_runtime()
+    L = C.CDLL(LIB_PATH)
+    vp, i32, f32, pd, sz = C.c_void_p, C.c_int, C.c_float, C.c_ssize_t, C.c_size_t
+    L.orbhip_extractor_create.argtypes = [C.POINTER(vp), i32, f32, i32, i32, i32, i32, i32, i32, i32]
+    L.orbhip_extractor_destroy.argtypes = [vp]
+    L.orbhip_extractor_destroy.restype = None
+    L.orbhip_levels.argtypes = [vp]
+    L.orbhip_scale_factor.argtypes = [vp]
+    L.orbhip_scale_factor.restype = f32
+    L.orbhip_table.argtypes = [vp, i32, vp]
+    L.orbhip_extract.argtypes = [vp, vp, i32, i32, pd, vp, vp, i32, vp]
+    L.orbhip_extract_batch.argtypes = [vp, vp, i32, i32, i32, pd, pd, vp, vp, i32, vp]
+    L.orbhip_extract_batch_device.argtypes = [vp, vp, i32, i32, i32, pd, pd, vp, vp, i32, vp]
+    L.orbhip_extractor_synchronize.argtypes = [vp]
+    L.orbhip_extractor_stream.argtypes = [vp]
+    L.orbhip_extractor_stream.restype = vp
+    L.orbhip_debug_get.argtypes = [vp, i32, i32, i32, vp, sz]
+    L.orbhip_level_geometry.argtypes = [vp, i32, vp]
+    L.orbhip_last_elapsed_ms.argtypes = [vp]
+    L.orbhip_last_elapsed_ms.restype = f32
+    L.orbhip_hamming_distance.argtypes = [vp, vp]
+    L.orbhip_matcher_create.argtypes = [C.POINTER(vp), i32]
+    L.orbhip_matcher_destroy.argtypes = [vp]
+    L.orbhip_matcher_destroy.restype = None
+    L.orbhip_matcher_synchronize.argtypes = [vp]
+    L.orbhip_matcher_stream.argtypes = [vp]
+    L.orbhip_matcher_stream.restype = vp
+    L.orbhip_knn2_device.argtypes = [vp, vp, i32, pd, vp, i32, pd, i32, i32, vp, vp, vp]
+    L.orbhip_knn2.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp, vp]
+    L.orbhip_knn2_merge_device.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+    L.orbhip_ratio_test_device.argtypes = [vp, vp, vp, i32, f32, i32, i32, vp]
+    L.orbhip_matcher_last_elapsed_ms.argtypes = [vp]
+    L.orbhip_matcher_last_elapsed_ms.restype = f32
+    L.orbhip_extractor_set_profiling.argtypes = [vp, i32]
+    L.orbhip_extractor_stage_times.argtypes = [vp, vp, vp]
+    L.orbhip_selftest.argtypes = [i32, vp, i32, i32, vp]
+    L.orbhip_device_count.argtypes = []
+    L.orbhip_version.restype = C.c_char_p
+    L.orbhip_last_error.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc < 0:
+        raise OrbhipError(rc, lib().orbhip_last_error().decode("utf-8", "replace"))
+    return rc

@@ -1,0 +1,36 @@
+// Launch interface of the extractor kernels (extract_kernels.hip).
+#ifndef ORBHIP_EXTRACT_KERNELS_H
+#define ORBHIP_EXTRACT_KERNELS_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "geom.h"
+
+struct OrbKeypointDev {  // same 28-byte layout as OrbKeypoint of the C ABI
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+};
+
+namespace orbk {
+void launch_level0(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* imgs, long long frame_stride,
+                   long long row_stride, uint8_t* pyr, const GeomDev* dg);
+void launch_resize(hipStream_t st, const GeomDev& hg, int batch, int level, uint8_t* pyr, const GeomDev* dg,
+                   const int* xofs, const uint32_t* xab, const uint32_t* ysrc, const uint32_t* yab);
+void launch_score(hipStream_t st, const GeomDev& hg, int batch, int level, const uint8_t* pyr, uint8_t* score,
+                  const GeomDev* dg);
+void launch_nms(hipStream_t st, const GeomDev& hg, int batch, int max_cell_h, const uint8_t* score, const GeomDev* dg,
+                const CellDesc* cells, uint32_t* cand, int* n_total, int* err);
+void launch_select(hipStream_t st, const GeomDev& hg, int batch, const GeomDev* dg, const CellDesc* cells,
+                   uint32_t* cand, const int* n_total, int* n_retain, uint32_t* lvl_list, int* lvl_count, int* err);
+void launch_orient(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* pyr, const GeomDev* dg,
+                   const uint32_t* lvl_list, const int* lvl_count, const int* disc, float* angles);
+void launch_blur(hipStream_t st, const GeomDev& hg, int batch, int level, const uint8_t* pyr, uint8_t* blur,
+                 const GeomDev* dg, const int taps[7]);
+void launch_describe(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* blur, const GeomDev* dg,
+                     const uint32_t* lvl_list, const int* lvl_count, const float* angles, const int8_t* pattern,
+                     OrbKeypointDev* kp_out, uint8_t* desc_out, int* n_out, int cap);
+void launch_test_atan2(hipStream_t st, const float* yx, float* out, int n);
+void launch_test_sincos(hipStream_t st, const float* in, float* out, int n);
+void launch_test_select(hipStream_t st, uint32_t* keys, int n, int nth);
+void launch_test_measure(hipStream_t st, const uint8_t* patches, int* out, int n);
+}  // namespace orbk
+#endif

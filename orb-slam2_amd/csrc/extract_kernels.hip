@@ -1,0 +1,680 @@
+// HIP kernels of the ORB extractor for gfx950.  Every kernel works on a batch of frames whose
+// pyramids stay resident in HBM; the block index carries (tile or cell or level, frame).
+//
+// Arithmetic contract (all integer unless stated): results must equal the reference's CPU path
+// (src/ORBextractor.cc) with OpenCV 2.4 scalar semantics bit for bit; the two float stages
+// (orientation polynomial, pattern rotation) are strict fp32 without contraction, so this file
+// is compiled with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "extract_kernels.h"
+#include "introselect.h"
+#include "sincos_port.h"
+
+namespace orbk {
+
+__device__ __forceinline__ int reflect101(int p, int n) {
+    if (p < 0) p = -p;
+    if (p >= n) p = 2 * n - 2 - p;
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Level 0: copyMakeBorder(image, temp, 16.., BORDER_REFLECT_101) (src/ORBextractor.cc:814).
+// One thread writes one aligned dword of the padded plane.
+__global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ imgs, long long frame_stride,
+                                                long long row_stride, uint8_t* __restrict__ pyr,
+                                                const GeomDev* __restrict__ g) {
+    const LevelGeom& L = g->lv[0];
+    const int dwx = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int f = blockIdx.z;
+    if (dwx * 4 >= L.stride || y >= L.ph) return;
+    const uint8_t* src = imgs + (long long)f * frame_stride;
+    const int sy = reflect101(y - ORB_EDGE, L.h);
+    uint32_t out = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const int x = dwx * 4 + b;
+        uint32_t v = 0;
+        if (x < L.w + 2 * ORB_EDGE) {
+            const int sx = reflect101(x - ORB_EDGE, L.w);
+            v = src[(long long)sy * row_stride + sx];
+        }
+        out |= v << (8 * b);
+    }
+    *(uint32_t*)(pyr + (long long)f * g->frame_bytes + L.plane_off + (long long)y * L.stride + dwx * 4) = out;
+}
+
+// Level l >= 1: resize(level l-1 ROI -> level l ROI, INTER_LINEAR) then copyMakeBorder
+// REFLECT_101 (src/ORBextractor.cc:800-807), fused: every padded pixel is computed from the
+// interior pixel it reflects to.  Coefficient tables hold OpenCV's 11-bit fixed-point weights.
+__global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, const GeomDev* __restrict__ g, int level,
+                                                const int* __restrict__ xofs, const uint32_t* __restrict__ xab,
+                                                const uint32_t* __restrict__ ysrc, const uint32_t* __restrict__ yab) {
+    const LevelGeom& L = g->lv[level];
+    const LevelGeom& P = g->lv[level - 1];
+    const int dwx = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int f = blockIdx.z;
+    if (dwx * 4 >= L.stride || y >= L.ph) return;
+    uint8_t* frame = pyr + (long long)f * g->frame_bytes;
+    const uint8_t* src = frame + P.plane_off + (long long)ORB_EDGE * P.stride + ORB_EDGE;
+    const int dy = reflect101(y - ORB_EDGE, L.h);
+    const uint32_t ys = ysrc[L.rz_y_off + dy], yb = yab[L.rz_y_off + dy];
+    const uint8_t* S0 = src + (long long)(ys & 0xffff) * P.stride;
+    const uint8_t* S1 = src + (long long)(ys >> 16) * P.stride;
+    const int b0 = yb & 0xffff, b1 = yb >> 16;
+    uint32_t out = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const int x = dwx * 4 + b;
+        uint32_t v = 0;
+        if (x < L.w + 2 * ORB_EDGE) {
+            const int dx = reflect101(x - ORB_EDGE, L.w);
+            const int sx = xofs[L.rz_x_off + dx];
+            const int sx1 = min(sx + 1, P.w - 1);
+            const uint32_t xa = xab[L.rz_x_off + dx];
+            const int a0 = xa & 0xffff, a1 = xa >> 16;
+            const int t0 = S0[sx] * a0 + S0[sx1] * a1;
+            const int t1 = S1[sx] * a0 + S1[sx1] * a1;
+            v = (uint32_t)((((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2) & 0xff;
+        }
+        out |= v << (8 * b);
+    }
+    *(uint32_t*)(frame + L.plane_off + (long long)y * L.stride + dwx * 4) = out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FAST-9/16 corner measure M(p) = max(A, B): A = max over the 16 arcs of nine contiguous circle
+// pixels of min(v - I_k), B the same for (I_k - v).  p is a corner at threshold t iff M > t and
+// cv::FAST's score for it is M - 1 whatever t was (fast_score.cpp cornerScore<16>), so one
+// measure plane per level serves both the fastTh pass and the threshold-7 retry of
+// src/ORBextractor.cc:607-614.
+__device__ __forceinline__ int fast_measure(const uint8_t* __restrict__ p, int s) {
+    const int v = p[0];
+    int d[16];
+    d[0] = v - p[3 * s];
+    d[1] = v - p[3 * s + 1];
+    d[2] = v - p[2 * s + 2];
+    d[3] = v - p[s + 3];
+    d[4] = v - p[3];
+    d[5] = v - p[-s + 3];
+    d[6] = v - p[-2 * s + 2];
+    d[7] = v - p[-3 * s + 1];
+    d[8] = v - p[-3 * s];
+    d[9] = v - p[-3 * s - 1];
+    d[10] = v - p[-2 * s - 2];
+    d[11] = v - p[-s - 3];
+    d[12] = v - p[-3];
+    d[13] = v - p[s - 3];
+    d[14] = v - p[2 * s - 2];
+    d[15] = v - p[3 * s - 1];
+    int mn3[16], mx3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        mn3[k] = min(d[k], min(d[(k + 1) & 15], d[(k + 2) & 15]));
+        mx3[k] = max(d[k], max(d[(k + 1) & 15], d[(k + 2) & 15]));
+    }
+    int A = -256, Bn = 256;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        A = max(A, min(mn3[k], min(mn3[(k + 3) & 15], mn3[(k + 6) & 15])));
+        Bn = min(Bn, max(mx3[k], max(mx3[(k + 3) & 15], mx3[(k + 6) & 15])));
+    }
+    return max(A, -Bn);
+}
+
+__global__ __launch_bounds__(256) void k_score(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score,
+                                               const GeomDev* __restrict__ g, int level) {
+    const LevelGeom& L = g->lv[level];
+    const int x = ORB_EDGE + blockIdx.x * 64 + threadIdx.x;
+    const int y = ORB_EDGE + blockIdx.y * 4 + threadIdx.y;
+    const int f = blockIdx.z;
+    if (x >= L.w - ORB_EDGE || y >= L.h - ORB_EDGE) return;
+    const long long off = (long long)f * g->frame_bytes + L.plane_off + (long long)(y + ORB_EDGE) * L.stride + (x + ORB_EDGE);
+    int m = fast_measure(pyr + off, L.stride);
+    score[off] = (uint8_t)min(max(m, 0), 255);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-cell non-max suppression, adaptive threshold and raster-ordered compaction
+// (src/ORBextractor.cc:599-614 + cv::FAST's NMS).  One workgroup per (cell, frame).
+// A pixel is kept at threshold t iff M > t and its score M-1 is strictly greater than the
+// score of each of its 8 neighbours, where a neighbour that is not a corner at t, or lies
+// outside the pixels this cell's FAST call examines, counts as 0.
+struct NmsCtx {
+    const uint8_t* S;  // measure plane at the level ROI origin
+    int stride;
+    int x0, y0, x1, y1;
+};
+
+__device__ __forceinline__ void nms_flags(const NmsCtx& c, int x, int y, int tHi, int tLo, bool& fHi, bool& fLo) {
+    const uint8_t* p = c.S + (long long)y * c.stride + x;
+    const int m = p[0];
+    fHi = m > tHi;
+    fLo = m > tLo;
+    if (!fHi && !fLo) return;
+    const int s = m - 1;
+    int nbHi = 0, nbLo = 0;
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+        for (int dx = -1; dx <= 1; dx++) {
+            if (dx == 0 && dy == 0) continue;
+            const int xx = x + dx, yy = y + dy;
+            if (xx < c.x0 || xx >= c.x1 || yy < c.y0 || yy >= c.y1) continue;
+            const int q = p[dy * c.stride + dx];
+            nbHi = max(nbHi, q > tHi ? q - 1 : 0);
+            nbLo = max(nbLo, q > tLo ? q - 1 : 0);
+        }
+    fHi = fHi && s > nbHi;
+    fLo = fLo && s > nbLo;
+}
+
+__global__ __launch_bounds__(256) void k_nms(const uint8_t* __restrict__ score, const GeomDev* __restrict__ g,
+                                             const CellDesc* __restrict__ cells, uint32_t* __restrict__ cand,
+                                             int* __restrict__ n_total, int* __restrict__ err) {
+    extern __shared__ int sh[];  // [0,ch): counts/offsets at fastTh, [ch,2ch): at 7, then 2*256 partials + 2
+    const int c = blockIdx.x, f = blockIdx.y;
+    const CellDesc cd = cells[c];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int* out_total = n_total + (long long)f * g->cells_per_frame + c;
+    if (cd.cw <= 0 || cd.ch <= 0) {
+        if (tid == 0) *out_total = 0;
+        return;
+    }
+    const LevelGeom& L = g->lv[cd.level];
+    NmsCtx ctx;
+    ctx.S = score + (long long)f * g->frame_bytes + L.plane_off + (long long)ORB_EDGE * L.stride + ORB_EDGE;
+    ctx.stride = L.stride;
+    ctx.x0 = cd.x0;
+    ctx.y0 = cd.y0;
+    ctx.x1 = cd.x0 + cd.cw;
+    ctx.y1 = cd.y0 + cd.ch;
+    const int ch = cd.ch, cw = cd.cw;
+    const int tHi = min(max(g->fast_th, 0), 255), tLo = 7;
+    int* cntHi = sh;
+    int* cntLo = sh + ch;
+    int* part = sh + 2 * ch;  // 512 partial sums, then 2 totals
+
+    for (int r = wave; r < ch; r += 4) {
+        int nHi = 0, nLo = 0;
+        for (int xb = 0; xb < cw; xb += 64) {
+            bool fHi = false, fLo = false;
+            if (xb + lane < cw) nms_flags(ctx, cd.x0 + xb + lane, cd.y0 + r, tHi, tLo, fHi, fLo);
+            nHi += __popcll(__ballot(fHi));
+            nLo += __popcll(__ballot(fLo));
+        }
+        if (lane == 0) {
+            cntHi[r] = nHi;
+            cntLo[r] = nLo;
+        }
+    }
+    __syncthreads();
+    // exclusive scan over rows: thread t owns rows [t*k, (t+1)*k)
+    const int k = (ch + 255) / 256;
+    const int r0 = min(tid * k, ch), r1 = min(r0 + k, ch);
+    int sHi = 0, sLo = 0;
+    for (int r = r0; r < r1; r++) {
+        sHi += cntHi[r];
+        sLo += cntLo[r];
+    }
+    part[tid] = sHi;
+    part[256 + tid] = sLo;
+    __syncthreads();
+    if (tid == 0) {
+        int aHi = 0, aLo = 0;
+        for (int t = 0; t < 256; t++) {
+            int vHi = part[t], vLo = part[256 + t];
+            part[t] = aHi;
+            part[256 + t] = aLo;
+            aHi += vHi;
+            aLo += vLo;
+        }
+        part[512] = aHi;
+        part[513] = aLo;
+    }
+    __syncthreads();
+    {
+        int aHi = part[tid], aLo = part[256 + tid];
+        for (int r = r0; r < r1; r++) {
+            int vHi = cntHi[r], vLo = cntLo[r];
+            cntHi[r] = aHi;
+            cntLo[r] = aLo;
+            aHi += vHi;
+            aLo += vLo;
+        }
+    }
+    __syncthreads();
+    const bool useLo = part[512] <= 3;  // "if(cellKeyPoints[i][j].size()<=3)" -> FAST(..., 7, true)
+    int total = useLo ? part[513] : part[512];
+    const int* offs = useLo ? cntLo : cntHi;
+    uint32_t* out = cand + (long long)f * g->cand_per_frame + cd.cand_off;
+    if (total > cd.cand_cap) {
+        if (tid == 0) atomicOr(err, 1);
+        total = cd.cand_cap;
+    }
+    for (int r = wave; r < ch; r += 4) {
+        int off = offs[r];
+        for (int xb = 0; xb < cw; xb += 64) {
+            bool fHi = false, fLo = false;
+            const int x = cd.x0 + xb + lane, y = cd.y0 + r;
+            if (xb + lane < cw) nms_flags(ctx, x, y, tHi, tLo, fHi, fLo);
+            const bool fl = useLo ? fLo : fHi;
+            const unsigned long long mask = __ballot(fl);
+            if (fl) {
+                const int pos = off + __popcll(mask & ((1ull << lane) - 1ull));
+                if (pos < cd.cand_cap) {
+                    const uint32_t s = (uint32_t)ctx.S[(long long)y * ctx.stride + x] - 1u;
+                    out[pos] = (s << 24) | ((uint32_t)(y - cd.ini_y) << 12) | (uint32_t)(x - cd.ini_x);
+                }
+            }
+            off += __popcll(mask);
+        }
+    }
+    if (tid == 0) *out_total = total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Quota redistribution (src/ORBextractor.cc:622-670), per-cell retainBest (:683-685), cell-major
+// concatenation in level coordinates (:687-694) and per-level retainBest (:697-701).
+// One workgroup per (level, frame).  The selections are serial algorithms (see introselect.h)
+// run by one lane on a list staged in LDS.
+#define SEL_BUF_KEYS 12032
+#define SEL_WAVE_KEYS (SEL_BUF_KEYS / 4)
+
+__global__ __launch_bounds__(256) void k_select(const GeomDev* __restrict__ g, const CellDesc* __restrict__ cells,
+                                                uint32_t* __restrict__ cand, const int* __restrict__ n_total,
+                                                int* __restrict__ n_retain, uint32_t* __restrict__ lvl_list,
+                                                int* __restrict__ lvl_count, int* __restrict__ err) {
+    __shared__ uint32_t buf[SEL_BUF_KEYS];
+    __shared__ int aux[ORB_MAX_CELLS_PER_LEVEL + 1];
+    const int level = blockIdx.x, f = blockIdx.y;
+    const LevelGeom& L = g->lv[level];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nCells = L.nCells;
+    const CellDesc* lc = cells + L.cell_base;
+    const int* tot = n_total + (long long)f * g->cells_per_frame + L.cell_base;
+    int* ret = n_retain + (long long)f * g->cells_per_frame + L.cell_base;
+    uint32_t* fcand = cand + (long long)f * g->cand_per_frame;
+
+    if (tid == 0) {
+        const int nfc = L.nfeaturesCell;
+        int nNoMore = 0, nToDistribute = 0;
+        for (int c = 0; c < nCells; c++) {
+            const bool skipped = lc[c].cw <= 0 || lc[c].ch <= 0;
+            const int nKeys = tot[c];
+            if (skipped) {
+                ret[c] = 0;
+                aux[c] = 0;
+            } else if (nKeys > nfc) {
+                ret[c] = nfc;
+                aux[c] = 0;
+            } else {
+                ret[c] = nKeys;
+                nToDistribute += nfc - nKeys;
+                aux[c] = 1;
+                nNoMore++;
+            }
+        }
+        while (nToDistribute > 0 && nNoMore < nCells) {
+            const int nNew = nfc + (int)ceilf((float)nToDistribute / (float)(nCells - nNoMore));
+            nToDistribute = 0;
+            for (int c = 0; c < nCells; c++)
+                if (!aux[c]) {
+                    const int nt = tot[c];
+                    if (nt > nNew) {
+                        ret[c] = nNew;
+                    } else {
+                        ret[c] = nt;
+                        nToDistribute += nNew - nt;
+                        aux[c] = 1;
+                        nNoMore++;
+                    }
+                }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // per-cell selection: wave w takes cells w, w+4, ...; uniform trip count so barriers match
+    uint32_t* wbuf = buf + wave * SEL_WAVE_KEYS;
+    for (int c0 = 0; c0 < nCells; c0 += 4) {
+        const int c = c0 + wave;
+        int n = 0, kk = 0;
+        uint32_t* list = nullptr;
+        if (c < nCells) {
+            n = tot[c];
+            kk = ret[c];
+            list = fcand + lc[c].cand_off;
+        }
+        const bool need = c < nCells && n > kk && kk > 0;
+        const bool staged = need && n <= SEL_WAVE_KEYS;
+        if (staged)
+            for (int i = lane; i < n; i += 64) wbuf[i] = list[i];
+        __syncthreads();
+        if (need && lane == 0) {
+            if (staged) orbsel::nth_element_desc(wbuf, n, kk);
+            else orbsel::nth_element_desc(list, n, kk);
+        }
+        __syncthreads();
+        if (staged)  // the whole permuted list goes back, so the cell list stays a permutation
+            for (int i = lane; i < n; i += 64) list[i] = wbuf[i];
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // offsets of the cells' retained prefixes in the level list
+    if (tid == 0) {
+        int a = 0;
+        for (int c = 0; c < nCells; c++) {
+            const int r = ret[c];
+            aux[c] = a;
+            a += r;
+        }
+        aux[nCells] = a;
+    }
+    __syncthreads();
+    int total = aux[nCells];
+    uint32_t* ll = lvl_list + (long long)f * g->lvl_per_frame + L.lvl_off;
+    if (total > L.lvl_cap) {
+        if (tid == 0) atomicOr(err, 2);
+        total = L.lvl_cap;
+    }
+    const bool lstaged = total <= SEL_BUF_KEYS;
+    uint32_t* dst = lstaged ? buf : ll;
+    for (int c = wave; c < nCells; c += 4) {
+        const int r = ret[c], o = aux[c];
+        const uint32_t* list = fcand + lc[c].cand_off;
+        const uint32_t add = ((uint32_t)lc[c].ini_y << 12) + (uint32_t)lc[c].ini_x;
+        for (int i = lane; i < r; i += 64)
+            if (o + i < total) dst[o + i] = list[i] + add;  // x, y of the cell image -> level coordinates
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int quota = L.quota;
+    if (total > quota && tid == 0) orbsel::nth_element_desc(dst, total, quota);
+    __syncthreads();
+    const int count = min(total, quota);
+    if (lstaged)
+        for (int i = tid; i < count; i += 256) ll[i] = buf[i];
+    if (tid == 0) lvl_count[f * g->nlevels + level] = count;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Output slot s of a frame belongs to level l iff slot_base[l] <= s < slot_base[l] + quota[l];
+// k = s - slot_base[l] is the keypoint's rank inside the level list.
+__device__ __forceinline__ bool slot_to_key(const GeomDev* g, const uint32_t* lvl_list, const int* lvl_count, int f,
+                                            int slot, int& level, int& k, uint32_t& key, int& out_index) {
+    if (slot >= g->nfeatures) return false;
+    int l = 0;
+    while (l + 1 < g->nlevels && g->lv[l + 1].slot_base <= slot) l++;
+    k = slot - g->lv[l].slot_base;
+    const int* cnt = lvl_count + f * g->nlevels;
+    if (k >= cnt[l]) return false;
+    int o = 0;
+    for (int i = 0; i < l; i++) o += cnt[i];
+    out_index = o + k;
+    level = l;
+    key = lvl_list[(long long)f * g->lvl_per_frame + g->lv[l].lvl_off + k];
+    return true;
+}
+
+// cv::fastAtan2 of OpenCV 2.4 (degrees), strict fp32.
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    const float scale = (float)(180.0 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale,
+                p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, ax + (float)2.2204460492503131e-16);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = __fdiv_rn(ax, ay + (float)2.2204460492503131e-16);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// IC_Angle (src/ORBextractor.cc:124-151): intensity-centroid moments over the radius-15 disc of
+// the UNBLURRED level image, one wave per keypoint, lanes striding over the 749 disc pixels.
+__global__ __launch_bounds__(256) void k_orient(const uint8_t* __restrict__ pyr, const GeomDev* __restrict__ g,
+                                                const uint32_t* __restrict__ lvl_list, const int* __restrict__ lvl_count,
+                                                const int* __restrict__ disc, float* __restrict__ angles) {
+    const int f = blockIdx.y;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    int level, k, oi;
+    uint32_t key;
+    if (!slot_to_key(g, lvl_list, lvl_count, f, slot, level, k, key, oi)) return;
+    const LevelGeom& L = g->lv[level];
+    const int x = key & 0xfff, y = (key >> 12) & 0xfff;
+    const uint8_t* center = pyr + (long long)f * g->frame_bytes + L.plane_off + (long long)(y + ORB_EDGE) * L.stride + (x + ORB_EDGE);
+    int m10 = 0, m01 = 0;
+    for (int i = lane; i < ORB_DISC_PIXELS; i += 64) {
+        const int uv = disc[i];
+        const int u = (int)(int8_t)(uv & 0xff), v = (int)(int8_t)((uv >> 8) & 0xff);
+        const int val = center[v * L.stride + u];
+        m10 += u * val;
+        m01 += v * val;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        m10 += __shfl_xor(m10, o);
+        m01 += __shfl_xor(m01, o);
+    }
+    if (lane == 0) angles[(long long)f * g->nfeatures + slot] = fast_atan2_deg((float)m01, (float)m10);
+}
+
+// ---------------------------------------------------------------------------------------------
+// GaussianBlur(level, level, Size(7,7), 2, 2, BORDER_REFLECT_101) on the level ROI
+// (src/ORBextractor.cc:760): separable integer taps, row pass in int32, column pass
+// (sum + 2^15) >> 16.  The filter border is the real 3-px ring of the padded plane.  Output goes
+// to a second plane whose 16-px margin is a copy of the unblurred margin: the in-place reference
+// leaves the margin unblurred and the descriptor pattern reaches up to 2 px into it.
+#define BLUR_TW 64
+#define BLUR_TH 16
+
+__global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
+                                              const GeomDev* __restrict__ g, int level, int t0, int t1, int t2, int t3) {
+    __shared__ uint8_t tile[BLUR_TH + 6][BLUR_TW + 8];
+    __shared__ int rows[BLUR_TH + 6][BLUR_TW];
+    const LevelGeom& L = g->lv[level];
+    const int f = blockIdx.z;
+    const int bx = blockIdx.x * BLUR_TW, by = blockIdx.y * BLUR_TH;  // padded coordinates
+    const long long base = (long long)f * g->frame_bytes + L.plane_off;
+    const uint8_t* src = pyr + base;
+    const int pw = L.w + 2 * ORB_EDGE, ph = L.ph;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < (BLUR_TH + 6) * (BLUR_TW + 6); i += 256) {
+        const int ty = i / (BLUR_TW + 6), tx = i - ty * (BLUR_TW + 6);
+        const int yy = min(max(by + ty - 3, 0), ph - 1), xx = min(max(bx + tx - 3, 0), pw - 1);
+        tile[ty][tx] = src[(long long)yy * L.stride + xx];
+    }
+    __syncthreads();
+    for (int i = tid; i < (BLUR_TH + 6) * BLUR_TW; i += 256) {
+        const int ty = i / BLUR_TW, tx = i - ty * BLUR_TW;
+        const uint8_t* p = &tile[ty][tx];
+        rows[ty][tx] = t0 * (p[0] + p[6]) + t1 * (p[1] + p[5]) + t2 * (p[2] + p[4]) + t3 * p[3];
+    }
+    __syncthreads();
+    for (int i = tid; i < BLUR_TH * BLUR_TW; i += 256) {
+        const int ty = i / BLUR_TW, tx = i - ty * BLUR_TW;
+        const int x = bx + tx, y = by + ty;
+        if (x >= L.stride || y >= ph) continue;
+        uint8_t v;
+        if (x >= ORB_EDGE && x < L.w + ORB_EDGE && y >= ORB_EDGE && y < L.h + ORB_EDGE) {
+            const int acc = t0 * (rows[ty][tx] + rows[ty + 6][tx]) + t1 * (rows[ty + 1][tx] + rows[ty + 5][tx]) +
+                            t2 * (rows[ty + 2][tx] + rows[ty + 4][tx]) + t3 * rows[ty + 3][tx];
+            const int r = (acc + 32768) >> 16;
+            v = (uint8_t)min(max(r, 0), 255);
+        } else {
+            v = x < pw ? tile[ty + 3][tx + 3] : 0;
+        }
+        blur[base + (long long)y * L.stride + x] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// computeOrbDescriptor (src/ORBextractor.cc:154-194) on the blurred plane + the output record of
+// operator() (:769-777).  32 lanes per keypoint, lane i produces descriptor byte i (8 tests).
+__global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ blur, const GeomDev* __restrict__ g,
+                                                  const uint32_t* __restrict__ lvl_list, const int* __restrict__ lvl_count,
+                                                  const float* __restrict__ angles, const int8_t* __restrict__ pattern,
+                                                  OrbKeypointDev* __restrict__ kp_out, uint8_t* __restrict__ desc_out,
+                                                  int* __restrict__ n_out, int cap) {
+    const int f = blockIdx.y;
+    const int slot = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int li = threadIdx.x & 31;
+    if (slot == 0 && li == 0) {
+        int n = 0;
+        for (int l = 0; l < g->nlevels; l++) n += lvl_count[f * g->nlevels + l];
+        n_out[f] = n;
+    }
+    int level, k, oi;
+    uint32_t key;
+    if (!slot_to_key(g, lvl_list, lvl_count, f, slot, level, k, key, oi)) return;
+    if (oi >= cap) return;
+    const LevelGeom& L = g->lv[level];
+    const int x = key & 0xfff, y = (key >> 12) & 0xfff;
+    const float angle_deg = angles[(long long)f * g->nfeatures + slot];
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    const float angle = angle_deg * factorPI;
+    const float a = orbtrig::cos_f<false>(angle), b = orbtrig::sin_f<false>(angle);
+    const int stride = L.stride;
+    const uint8_t* center = blur + (long long)f * g->frame_bytes + L.plane_off + (long long)(y + ORB_EDGE) * stride + (x + ORB_EDGE);
+    const int8_t* pat = pattern + li * 32;
+    uint32_t val = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const float x0 = (float)pat[4 * j], y0 = (float)pat[4 * j + 1], x1 = (float)pat[4 * j + 2], y1 = (float)pat[4 * j + 3];
+        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+        const int v0 = center[r0 * stride + c0], v1 = center[r1 * stride + c1];
+        val |= (uint32_t)(v0 < v1) << j;
+    }
+    const long long o = (long long)f * cap + oi;
+    desc_out[o * 32 + li] = (uint8_t)val;
+    if (li < 7) {
+        uint32_t w;
+        const float scale = L.scale;
+        switch (li) {
+            case 0: w = __float_as_uint(level ? __fmul_rn((float)x, scale) : (float)x); break;
+            case 1: w = __float_as_uint(level ? __fmul_rn((float)y, scale) : (float)y); break;
+            case 2: w = __float_as_uint(L.kp_size); break;
+            case 3: w = __float_as_uint(angle_deg); break;
+            case 4: w = __float_as_uint((float)(key >> 24)); break;
+            case 5: w = (uint32_t)level; break;
+            default: w = 0xffffffffu; break;
+        }
+        ((uint32_t*)(kp_out + o))[li] = w;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device self-tests of the arithmetic helpers (test instrumentation).
+__global__ void k_test_atan2(const float* yx, float* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = fast_atan2_deg(yx[2 * i], yx[2 * i + 1]);
+}
+__global__ void k_test_sincos(const float* in, float* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        out[2 * i] = orbtrig::cos_f<false>(in[i]);
+        out[2 * i + 1] = orbtrig::sin_f<false>(in[i]);
+    }
+}
+__global__ void k_test_select(uint32_t* keys, int n, int nth) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) orbsel::nth_element_desc(keys, n, nth);
+}
+__global__ void k_test_measure(const uint8_t* patches, int* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = fast_measure(patches + (long long)i * 49 + 24, 7);
+}
+
+}  // namespace orbk
+
+// ---------------------------------------------------------------------------------------------
+// Launchers (host side of this translation unit).
+namespace orbk {
+
+void launch_level0(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* imgs, long long frame_stride,
+                   long long row_stride, uint8_t* pyr, const GeomDev* dg) {
+    const LevelGeom& L = hg.lv[0];
+    dim3 grid((L.stride / 4 + 63) / 64, (L.ph + 3) / 4, batch), block(64, 4);
+    hipLaunchKernelGGL(k_level0, grid, block, 0, st, imgs, frame_stride, row_stride, pyr, dg);
+}
+
+void launch_resize(hipStream_t st, const GeomDev& hg, int batch, int level, uint8_t* pyr, const GeomDev* dg,
+                   const int* xofs, const uint32_t* xab, const uint32_t* ysrc, const uint32_t* yab) {
+    const LevelGeom& L = hg.lv[level];
+    dim3 grid((L.stride / 4 + 63) / 64, (L.ph + 3) / 4, batch), block(64, 4);
+    hipLaunchKernelGGL(k_resize, grid, block, 0, st, pyr, dg, level, xofs, xab, ysrc, yab);
+}
+
+void launch_score(hipStream_t st, const GeomDev& hg, int batch, int level, const uint8_t* pyr, uint8_t* score,
+                  const GeomDev* dg) {
+    const LevelGeom& L = hg.lv[level];
+    const int iw = L.w - 2 * ORB_EDGE, ih = L.h - 2 * ORB_EDGE;
+    if (iw <= 0 || ih <= 0) return;
+    dim3 grid((iw + 63) / 64, (ih + 3) / 4, batch), block(64, 4);
+    hipLaunchKernelGGL(k_score, grid, block, 0, st, pyr, score, dg, level);
+}
+
+void launch_nms(hipStream_t st, const GeomDev& hg, int batch, int max_cell_h, const uint8_t* score, const GeomDev* dg,
+                const CellDesc* cells, uint32_t* cand, int* n_total, int* err) {
+    dim3 grid(hg.cells_per_frame, batch), block(256);
+    const size_t lds = (size_t)(2 * max_cell_h + 516) * sizeof(int);
+    hipLaunchKernelGGL(k_nms, grid, block, lds, st, score, dg, cells, cand, n_total, err);
+}
+
+void launch_select(hipStream_t st, const GeomDev& hg, int batch, const GeomDev* dg, const CellDesc* cells,
+                   uint32_t* cand, const int* n_total, int* n_retain, uint32_t* lvl_list, int* lvl_count, int* err) {
+    dim3 grid(hg.nlevels, batch), block(256);
+    hipLaunchKernelGGL(k_select, grid, block, 0, st, dg, cells, cand, n_total, n_retain, lvl_list, lvl_count, err);
+}
+
+void launch_orient(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* pyr, const GeomDev* dg,
+                   const uint32_t* lvl_list, const int* lvl_count, const int* disc, float* angles) {
+    dim3 grid((hg.nfeatures + 3) / 4, batch), block(256);
+    hipLaunchKernelGGL(k_orient, grid, block, 0, st, pyr, dg, lvl_list, lvl_count, disc, angles);
+}
+
+void launch_blur(hipStream_t st, const GeomDev& hg, int batch, int level, const uint8_t* pyr, uint8_t* blur,
+                 const GeomDev* dg, const int taps[7]) {
+    const LevelGeom& L = hg.lv[level];
+    dim3 grid((L.stride + BLUR_TW - 1) / BLUR_TW, (L.ph + BLUR_TH - 1) / BLUR_TH, batch), block(256);
+    hipLaunchKernelGGL(k_blur, grid, block, 0, st, pyr, blur, dg, level, taps[0], taps[1], taps[2], taps[3]);
+}
+
+void launch_describe(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* blur, const GeomDev* dg,
+                     const uint32_t* lvl_list, const int* lvl_count, const float* angles, const int8_t* pattern,
+                     OrbKeypointDev* kp_out, uint8_t* desc_out, int* n_out, int cap) {
+    dim3 grid((hg.nfeatures + 7) / 8, batch), block(256);
+    hipLaunchKernelGGL(k_describe, grid, block, 0, st, blur, dg, lvl_list, lvl_count, angles, pattern, kp_out, desc_out,
+                       n_out, cap);
+}
+
+void launch_test_atan2(hipStream_t st, const float* yx, float* out, int n) {
+    hipLaunchKernelGGL(k_test_atan2, dim3((n + 255) / 256), dim3(256), 0, st, yx, out, n);
+}
+void launch_test_sincos(hipStream_t st, const float* in, float* out, int n) {
+    hipLaunchKernelGGL(k_test_sincos, dim3((n + 255) / 256), dim3(256), 0, st, in, out, n);
+}
+void launch_test_select(hipStream_t st, uint32_t* keys, int n, int nth) {
+    hipLaunchKernelGGL(k_test_select, dim3(1), dim3(64), 0, st, keys, n, nth);
+}
+void launch_test_measure(hipStream_t st, const uint8_t* patches, int* out, int n) {
+    hipLaunchKernelGGL(k_test_measure, dim3((n + 255) / 256), dim3(256), 0, st, patches, out, n);
+}
+
+}  // namespace orbk

@@ -1,0 +1,678 @@
+// Host side of the extractor: constructor tables, level/cell geometry, device arenas and the
+// kernel sequence of one chunk of frames.  Implements the orbhip_extractor_* / orbhip_extract*
+// entry points of include/orbhip.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/orbhip.h"
+#include "common.h"
+#include "extract_kernels.h"
+
+#define ORB_NSTAGES 8  // level0, resize, score, nms, select, orient, blur, describe
+
+namespace {
+
+const signed char kPattern[1024] = {
+#include "../../include/orb_pattern.inc"
+};
+
+inline int round_half_even(double v) { return (int)std::nearbyint(v); }  // cvRound
+inline int floor_int(double v) { int i = (int)v; return i - (i > v); }
+inline int ceil_int(double v) { int i = (int)v; return i + (i < v); }
+
+struct DeviceBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return ORBHIP_OK;
+        if (p) hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        if (hipMalloc(&p, need) != hipSuccess) return orb_fail(ORBHIP_ENOMEM, "hipMalloc of %zu bytes failed", need);
+        bytes = need;
+        return ORBHIP_OK;
+    }
+    void release() {
+        if (p) hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+}  // namespace
+
+struct orbhip_extractor {
+    // constructor state (src/ORBextractor.cc:457-511)
+    int nfeatures;
+    double scaleFactor;
+    int nlevels, scoreType, fastTh;
+    std::vector<int> featuresPerLevel;
+    std::vector<float> scale, invScale;
+    int umax[16];
+    int gtaps[7];
+
+    int device;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_ms = 0.f;
+    int max_batch;
+    // per-stage timing (bench instrumentation): events bracket each kernel group of a chunk
+    bool profiling = false;
+    std::vector<hipEvent_t> prof_ev;           // (ORB_NSTAGES + 1) events per chunk of the last call
+    int prof_chunks = 0;
+    float stage_ms[ORB_NSTAGES] = {0};
+    int stage_launches[ORB_NSTAGES] = {0};
+
+    // geometry of the current image size
+    int cur_rows = 0, cur_cols = 0;
+    GeomDev hg;
+    std::vector<CellDesc> hcells;
+    int max_cell_h = 0;
+    int last_batch = 0;  // frames of the last chunk (for the stage taps)
+
+    DeviceBuf d_geom, d_cells, d_xofs, d_xab, d_ysrc, d_yab, d_disc, d_pattern;
+    DeviceBuf d_pyr, d_blur, d_score, d_cand, d_ntotal, d_nretain, d_lvl, d_lvlcount, d_angles, d_err;
+    DeviceBuf d_img, d_kp, d_desc, d_n;  // staging of the host-pointer entry points
+};
+
+namespace {
+
+// ORBextractor::ORBextractor: scale tables, per-level quotas, umax.
+int build_tables(orbhip_extractor* e) {
+    const int nlevels = e->nlevels;
+    e->scale.assign(nlevels, 1.f);
+    for (int i = 1; i < nlevels; i++) e->scale[i] = (float)(e->scale[i - 1] * e->scaleFactor);
+    const float inv = (float)(1.0f / e->scaleFactor);
+    e->invScale.assign(nlevels, 1.f);
+    for (int i = 1; i < nlevels; i++) e->invScale[i] = e->invScale[i - 1] * inv;
+
+    e->featuresPerLevel.assign(nlevels, 0);
+    const float factor = (float)(1.0 / e->scaleFactor);
+    float desired = e->nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nlevels));
+    int sum = 0;
+    for (int l = 0; l < nlevels - 1; l++) {
+        e->featuresPerLevel[l] = round_half_even(desired);
+        sum += e->featuresPerLevel[l];
+        desired *= factor;
+    }
+    e->featuresPerLevel[nlevels - 1] = std::max(e->nfeatures - sum, 0);
+
+    // rows of the radius-15 disc (src/ORBextractor.cc:495-510)
+    const int hp = ORB_HALF_PATCH;
+    const int vmax = floor_int(hp * std::sqrt(2.f) / 2 + 1);
+    const int vmin = ceil_int(hp * std::sqrt(2.f) / 2);
+    for (int v = 0; v <= vmax; ++v) e->umax[v] = round_half_even(std::sqrt((double)hp * hp - v * v));
+    for (int v = hp, v0 = 0; v >= vmin; --v) {
+        while (e->umax[v0] == e->umax[v0 + 1]) ++v0;
+        e->umax[v] = v0;
+        ++v0;
+    }
+    // 8-bit fixed-point taps of getGaussianKernel(7, 2): exp(-x^2/8) in double, stored as float,
+    // normalised by the float sum, times 256, rounded half to even.
+    float cf[7];
+    double s = 0;
+    for (int i = 0; i < 7; i++) {
+        const double x = i - 3.0;
+        cf[i] = (float)std::exp(-0.5 / 4.0 * x * x);
+        s += cf[i];
+    }
+    s = 1. / s;
+    for (int i = 0; i < 7; i++) {
+        cf[i] = (float)(cf[i] * s);
+        e->gtaps[i] = round_half_even((double)cf[i] * 256);
+    }
+    return ORBHIP_OK;
+}
+
+// Level sizes (src/ORBextractor.cc:786), cell grid (:527-547,560-599), arena layout, resize tables.
+int build_geometry(orbhip_extractor* e, int rows, int cols, GeomDev& g, std::vector<CellDesc>& cells,
+                   std::vector<int>& xofs, std::vector<uint32_t>& xab, std::vector<uint32_t>& ysrc,
+                   std::vector<uint32_t>& yab, int& max_cell_h) {
+    memset(&g, 0, sizeof(g));
+    cells.clear();
+    xofs.clear();
+    xab.clear();
+    ysrc.clear();
+    yab.clear();
+    g.nlevels = e->nlevels;
+    g.fast_th = e->fastTh;
+    if (cols > ORB_MAX_DIM || rows > ORB_MAX_DIM) return orb_fail(ORBHIP_EUNSUPPORTED, "image larger than %d", ORB_MAX_DIM);
+    long long plane_off = 0, cand_off = 0, lvl_off = 0;
+    int slot = 0;
+    max_cell_h = 1;
+    const float imageRatio = (float)cols / rows;  // cols, rows of level 0
+    for (int l = 0; l < e->nlevels; l++) {
+        LevelGeom& L = g.lv[l];
+        const float s = e->invScale[l];
+        L.w = round_half_even((float)cols * s);
+        L.h = round_half_even((float)rows * s);
+        if (L.w < 2 * ORB_EDGE + 1 || L.h < 2 * ORB_EDGE + 1)
+            return orb_fail(ORBHIP_EGEOM, "level %d is %dx%d: no interior inside the 16-px border", l, L.w, L.h);
+        L.stride = (L.w + 2 * ORB_EDGE + 63) & ~63;
+        L.ph = L.h + 2 * ORB_EDGE;
+        L.plane_off = plane_off;
+        plane_off += ((long long)L.stride * L.ph + 255) & ~255LL;
+        L.quota = e->featuresPerLevel[l];
+        L.scale = e->scale[l];
+        L.kp_size = (float)(int)(31 * e->scale[l]);
+        L.slot_base = slot;
+        slot += L.quota;
+
+        L.cols = (int)std::sqrt((float)L.quota / (5 * imageRatio));
+        L.rows = (int)(imageRatio * L.cols);
+        if (L.cols < 1 || L.rows < 1)
+            return orb_fail(ORBHIP_EGEOM, "level %d: %d features give a %dx%d cell grid", l, L.quota, L.cols, L.rows);
+        const int minB = ORB_EDGE, maxBX = L.w - ORB_EDGE, maxBY = L.h - ORB_EDGE;
+        const int W = maxBX - minB, H = maxBY - minB;
+        L.cellW = (int)std::ceil((float)W / L.cols);
+        L.cellH = (int)std::ceil((float)H / L.rows);
+        L.nCells = L.rows * L.cols;
+        if (L.nCells > ORB_MAX_CELLS_PER_LEVEL) return orb_fail(ORBHIP_EUNSUPPORTED, "level %d has %d cells", l, L.nCells);
+        L.nfeaturesCell = (int)std::ceil((float)L.quota / L.nCells);
+        L.cell_base = (int)cells.size();
+        long long level_cand = 0;
+        for (int i = 0; i < L.rows; i++)
+            for (int j = 0; j < L.cols; j++) {
+                CellDesc c;
+                memset(&c, 0, sizeof(c));
+                c.level = l;
+                c.index = i * L.cols + j;
+                c.ini_x = minB + j * L.cellW - 3;
+                c.ini_y = minB + i * L.cellH - 3;
+                c.x0 = c.ini_x + 3;
+                c.y0 = c.ini_y + 3;
+                // examined pixels: columns 3 .. hX-4 of the cell image, hX = cellW+6, or up to the
+                // border for the last column (hX = maxBorderX + 3 - iniX); same for rows.
+                c.cw = (j == L.cols - 1) ? maxBX - c.x0 : L.cellW;
+                c.ch = (i == L.rows - 1) ? maxBY - c.y0 : L.cellH;
+                // the reference skips a last row/column whose cell image is empty (hX <= 0)
+                const int hX = (j == L.cols - 1) ? maxBX + 3 - c.ini_x : L.cellW + 6;
+                const int hY = (i == L.rows - 1) ? maxBY + 3 - c.ini_y : L.cellH + 6;
+                if (hX <= 0 || hY <= 0) {
+                    c.cw = c.ch = 0;
+                } else {
+                    // a cell image reaching past the level image makes cv::Mat::colRange throw
+                    if (c.ini_x + hX > L.w || c.ini_y + hY > L.h)
+                        return orb_fail(ORBHIP_EGEOM, "level %d: cell grid does not fit the %dx%d level", l, L.w, L.h);
+                    if (c.cw < 0) c.cw = 0;  // 0 < hX <= 6: an image with no examined pixel
+                    if (c.ch < 0) c.ch = 0;
+                }
+                c.cand_off = cand_off;
+                c.cand_cap = ((std::max(c.cw, 0) + 1) / 2) * ((std::max(c.ch, 0) + 1) / 2);
+                cand_off += c.cand_cap;
+                level_cand += c.cand_cap;
+                max_cell_h = std::max(max_cell_h, c.ch);
+                cells.push_back(c);
+            }
+        const long long quota_bound = (long long)L.nfeaturesCell * L.nCells + (long long)L.nCells * (L.nCells + 1) / 2;
+        L.lvl_cap = (int)std::min<long long>(level_cand, quota_bound);
+        L.lvl_off = lvl_off;
+        lvl_off += L.lvl_cap;
+
+        // cv::resize INTER_LINEAR coefficient tables for level l-1 -> l
+        L.rz_x_off = (int)xofs.size();
+        L.rz_y_off = (int)ysrc.size();
+        if (l > 0) {
+            const LevelGeom& P = g.lv[l - 1];
+            const double scale_x = 1. / ((double)L.w / P.w), scale_y = 1. / ((double)L.h / P.h);
+            for (int dx = 0; dx < L.w; dx++) {
+                float fx = (float)((dx + 0.5) * scale_x - 0.5);
+                int sx = floor_int(fx);
+                fx -= sx;
+                if (sx < 0) { fx = 0; sx = 0; }
+                if (sx >= P.w - 1) { fx = 0; sx = P.w - 1; }
+                const int a0 = std::min(std::max(round_half_even((1.f - fx) * 2048), -32768), 32767);
+                const int a1 = std::min(std::max(round_half_even(fx * 2048), -32768), 32767);
+                xofs.push_back(sx);
+                xab.push_back((uint32_t)(a0 & 0xffff) | ((uint32_t)(a1 & 0xffff) << 16));
+            }
+            for (int dy = 0; dy < L.h; dy++) {
+                float fy = (float)((dy + 0.5) * scale_y - 0.5);
+                const int sy = floor_int(fy);
+                fy -= sy;
+                const int sy0 = std::min(std::max(sy, 0), P.h - 1), sy1 = std::min(std::max(sy + 1, 0), P.h - 1);
+                const int b0 = std::min(std::max(round_half_even((1.f - fy) * 2048), -32768), 32767);
+                const int b1 = std::min(std::max(round_half_even(fy * 2048), -32768), 32767);
+                ysrc.push_back((uint32_t)sy0 | ((uint32_t)sy1 << 16));
+                yab.push_back((uint32_t)(b0 & 0xffff) | ((uint32_t)(b1 & 0xffff) << 16));
+            }
+        }
+    }
+    g.nfeatures = slot;
+    g.cells_per_frame = (int)cells.size();
+    g.frame_bytes = plane_off;
+    g.cand_per_frame = cand_off;
+    g.lvl_per_frame = lvl_off;
+    return ORBHIP_OK;
+}
+
+#define HIPCHK(call)                                                                         \
+    do {                                                                                     \
+        hipError_t err__ = (call);                                                           \
+        if (err__ != hipSuccess)                                                             \
+            return orb_fail(ORBHIP_EHIP, "%s failed: %s", #call, hipGetErrorString(err__)); \
+    } while (0)
+
+int upload(DeviceBuf& b, const void* src, size_t bytes, hipStream_t st) {
+    int rc = b.ensure(std::max<size_t>(bytes, 16));
+    if (rc) return rc;
+    if (bytes) {
+        HIPCHK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    return ORBHIP_OK;
+}
+
+// (Re)builds geometry for an image size and makes the arenas large enough for `batch` frames.
+int set_size(orbhip_extractor* e, int rows, int cols, int batch) {
+    if (rows != e->cur_rows || cols != e->cur_cols) {
+        GeomDev g;
+        std::vector<CellDesc> cells;
+        std::vector<int> xofs;
+        std::vector<uint32_t> xab, ysrc, yab;
+        int mch = 0;
+        int rc = build_geometry(e, rows, cols, g, cells, xofs, xab, ysrc, yab, mch);
+        if (rc) return rc;
+        if ((rc = upload(e->d_geom, &g, sizeof(g), e->stream))) return rc;
+        if ((rc = upload(e->d_cells, cells.data(), cells.size() * sizeof(CellDesc), e->stream))) return rc;
+        if ((rc = upload(e->d_xofs, xofs.data(), xofs.size() * sizeof(int), e->stream))) return rc;
+        if ((rc = upload(e->d_xab, xab.data(), xab.size() * sizeof(uint32_t), e->stream))) return rc;
+        if ((rc = upload(e->d_ysrc, ysrc.data(), ysrc.size() * sizeof(uint32_t), e->stream))) return rc;
+        if ((rc = upload(e->d_yab, yab.data(), yab.size() * sizeof(uint32_t), e->stream))) return rc;
+        e->hg = g;
+        e->hcells.swap(cells);
+        e->max_cell_h = mch;
+        e->cur_rows = rows;
+        e->cur_cols = cols;
+    }
+    const GeomDev& g = e->hg;
+    const size_t B = (size_t)batch;
+    int rc;
+    if ((rc = e->d_pyr.ensure(B * g.frame_bytes))) return rc;
+    if ((rc = e->d_blur.ensure(B * g.frame_bytes))) return rc;
+    if ((rc = e->d_score.ensure(B * g.frame_bytes))) return rc;
+    if ((rc = e->d_cand.ensure(std::max<size_t>(B * g.cand_per_frame * 4, 16)))) return rc;
+    if ((rc = e->d_ntotal.ensure(B * g.cells_per_frame * 4))) return rc;
+    if ((rc = e->d_nretain.ensure(B * g.cells_per_frame * 4))) return rc;
+    if ((rc = e->d_lvl.ensure(std::max<size_t>(B * g.lvl_per_frame * 4, 16)))) return rc;
+    if ((rc = e->d_lvlcount.ensure(B * g.nlevels * 4))) return rc;
+    if ((rc = e->d_angles.ensure(B * g.nfeatures * 4))) return rc;
+    return ORBHIP_OK;
+}
+
+// The kernel sequence for `batch` frames whose images, outputs and count array are in device memory.
+int run_chunk(orbhip_extractor* e, const uint8_t* d_imgs, int batch, long long row_stride, long long frame_stride,
+              OrbKeypoint* d_kp, uint8_t* d_desc, int cap, int* d_n) {
+    const GeomDev& g = e->hg;
+    const GeomDev* dg = e->d_geom.as<GeomDev>();
+    hipStream_t st = e->stream;
+    uint8_t* pyr = e->d_pyr.as<uint8_t>();
+    hipEvent_t* pev = nullptr;
+    if (e->profiling) {
+        const size_t need = (size_t)(e->prof_chunks + 1) * (ORB_NSTAGES + 1);
+        while (e->prof_ev.size() < need) {
+            hipEvent_t ev;
+            HIPCHK(hipEventCreate(&ev));
+            e->prof_ev.push_back(ev);
+        }
+        pev = &e->prof_ev[(size_t)e->prof_chunks * (ORB_NSTAGES + 1)];
+        e->prof_chunks++;
+    }
+#define STAGE_MARK(i) do { if (pev) HIPCHK(hipEventRecord(pev[i], st)); } while (0)
+    STAGE_MARK(0);
+    orbk::launch_level0(st, g, batch, d_imgs, frame_stride, row_stride, pyr, dg);
+    STAGE_MARK(1);
+    for (int l = 1; l < g.nlevels; l++)
+        orbk::launch_resize(st, g, batch, l, pyr, dg, e->d_xofs.as<int>(), e->d_xab.as<uint32_t>(),
+                            e->d_ysrc.as<uint32_t>(), e->d_yab.as<uint32_t>());
+    STAGE_MARK(2);
+    for (int l = 0; l < g.nlevels; l++) orbk::launch_score(st, g, batch, l, pyr, e->d_score.as<uint8_t>(), dg);
+    STAGE_MARK(3);
+    orbk::launch_nms(st, g, batch, e->max_cell_h, e->d_score.as<uint8_t>(), dg, e->d_cells.as<CellDesc>(),
+                     e->d_cand.as<uint32_t>(), e->d_ntotal.as<int>(), e->d_err.as<int>());
+    STAGE_MARK(4);
+    orbk::launch_select(st, g, batch, dg, e->d_cells.as<CellDesc>(), e->d_cand.as<uint32_t>(), e->d_ntotal.as<int>(),
+                        e->d_nretain.as<int>(), e->d_lvl.as<uint32_t>(), e->d_lvlcount.as<int>(), e->d_err.as<int>());
+    STAGE_MARK(5);
+    orbk::launch_orient(st, g, batch, pyr, dg, e->d_lvl.as<uint32_t>(), e->d_lvlcount.as<int>(), e->d_disc.as<int>(),
+                        e->d_angles.as<float>());
+    STAGE_MARK(6);
+    for (int l = 0; l < g.nlevels; l++) orbk::launch_blur(st, g, batch, l, pyr, e->d_blur.as<uint8_t>(), dg, e->gtaps);
+    STAGE_MARK(7);
+    orbk::launch_describe(st, g, batch, e->d_blur.as<uint8_t>(), dg, e->d_lvl.as<uint32_t>(), e->d_lvlcount.as<int>(),
+                          e->d_angles.as<float>(), e->d_pattern.as<int8_t>(), (OrbKeypointDev*)d_kp, d_desc, d_n, cap);
+    STAGE_MARK(8);
+#undef STAGE_MARK
+    HIPCHK(hipGetLastError());
+    e->last_batch = batch;
+    return ORBHIP_OK;
+}
+
+int check_call(orbhip_extractor* e, int batch, int rows, int cols, int cap) {
+    if (!e) return orb_fail(ORBHIP_EINVAL, "null extractor");
+    if (batch < 0 || rows < 0 || cols < 0) return orb_fail(ORBHIP_EINVAL, "negative size");
+    if (cap < e->nfeatures) return orb_fail(ORBHIP_ECAP, "cap %d < nfeatures %d", cap, e->nfeatures);
+    if (e->scoreType != ORBHIP_FAST_SCORE) return orb_fail(ORBHIP_EUNSUPPORTED, "HARRIS_SCORE is not implemented");
+    return ORBHIP_OK;
+}
+
+int check_device_error(orbhip_extractor* e) {
+    int herr = 0;
+    HIPCHK(hipMemcpy(&herr, e->d_err.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (herr) {
+        hipMemset(e->d_err.p, 0, sizeof(int));
+        return orb_fail(ORBHIP_ECAP, "device arena overflow (flags %d)", herr);
+    }
+    return ORBHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int orbhip_extractor_create(orbhip_extractor** out, int nfeatures, float scale_factor, int nlevels, int score_type,
+                            int fast_th, int device, int max_width, int max_height, int max_batch) {
+    if (!out) return orb_fail(ORBHIP_EINVAL, "null out pointer");
+    *out = nullptr;
+    if (nfeatures < 1 || nlevels < 1 || nlevels > ORBHIP_MAX_LEVELS || !(scale_factor > 1.0f) || max_batch < 1 ||
+        max_width < 1 || max_height < 1 || (score_type != ORBHIP_FAST_SCORE && score_type != ORBHIP_HARRIS_SCORE))
+        return orb_fail(ORBHIP_EINVAL, "bad extractor parameters");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return orb_fail(ORBHIP_ENODEV, "no HIP device");
+    if (device < 0 || device >= ndev) return orb_fail(ORBHIP_EINVAL, "device %d of %d", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    orbhip_extractor* e = new orbhip_extractor;
+    e->nfeatures = nfeatures;
+    e->scaleFactor = scale_factor;  // double member initialised from a float, include/ORBextractor.h:62
+    e->nlevels = nlevels;
+    e->scoreType = score_type;
+    e->fastTh = fast_th;
+    e->device = device;
+    e->max_batch = max_batch;
+    build_tables(e);
+    int rc = ORBHIP_OK;
+    do {
+        if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess) {
+            rc = orb_fail(ORBHIP_EHIP, "stream/event creation failed");
+            break;
+        }
+        // disc pixel table in the order IC_Angle visits them (order is irrelevant to the integer sums)
+        std::vector<int> disc;
+        for (int v = -ORB_HALF_PATCH; v <= ORB_HALF_PATCH; v++) {
+            const int d = e->umax[v < 0 ? -v : v];
+            for (int u = -d; u <= d; u++) disc.push_back((u & 0xff) | ((v & 0xff) << 8));
+        }
+        if ((int)disc.size() != ORB_DISC_PIXELS) {
+            rc = orb_fail(ORBHIP_EINVAL, "disc has %zu pixels", disc.size());
+            break;
+        }
+        if ((rc = upload(e->d_disc, disc.data(), disc.size() * sizeof(int), e->stream))) break;
+        if ((rc = upload(e->d_pattern, kPattern, sizeof(kPattern), e->stream))) break;
+        if ((rc = e->d_err.ensure(16))) break;
+        if (hipMemset(e->d_err.p, 0, 16) != hipSuccess) {
+            rc = orb_fail(ORBHIP_EHIP, "hipMemset failed");
+            break;
+        }
+        if ((rc = set_size(e, max_height, max_width, max_batch))) break;
+    } while (0);
+    if (rc) {
+        orbhip_extractor_destroy(e);
+        return rc;
+    }
+    *out = e;
+    return ORBHIP_OK;
+}
+
+void orbhip_extractor_destroy(orbhip_extractor* e) {
+    if (!e) return;
+    hipSetDevice(e->device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    DeviceBuf* bufs[] = {&e->d_geom, &e->d_cells, &e->d_xofs, &e->d_xab, &e->d_ysrc, &e->d_yab, &e->d_disc, &e->d_pattern,
+                         &e->d_pyr, &e->d_blur, &e->d_score, &e->d_cand, &e->d_ntotal, &e->d_nretain, &e->d_lvl,
+                         &e->d_lvlcount, &e->d_angles, &e->d_err, &e->d_img, &e->d_kp, &e->d_desc, &e->d_n};
+    for (DeviceBuf* b : bufs) b->release();
+    for (hipEvent_t ev : e->prof_ev) hipEventDestroy(ev);
+    if (e->ev0) hipEventDestroy(e->ev0);
+    if (e->ev1) hipEventDestroy(e->ev1);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int orbhip_levels(const orbhip_extractor* e) { return e ? e->nlevels : ORBHIP_EINVAL; }
+float orbhip_scale_factor(const orbhip_extractor* e) { return e ? (float)e->scaleFactor : 0.f; }
+
+int orbhip_table(const orbhip_extractor* e, int which, void* out) {
+    if (!e || !out) return ORBHIP_EINVAL;
+    switch (which) {
+        case 0: memcpy(out, e->featuresPerLevel.data(), sizeof(int) * e->nlevels); return e->nlevels;
+        case 1: memcpy(out, e->scale.data(), sizeof(float) * e->nlevels); return e->nlevels;
+        case 2: memcpy(out, e->invScale.data(), sizeof(float) * e->nlevels); return e->nlevels;
+        case 3: memcpy(out, e->umax, sizeof(int) * 16); return 16;
+        case 4: memcpy(out, e->gtaps, sizeof(int) * 7); return 7;
+    }
+    return ORBHIP_EINVAL;
+}
+
+int orbhip_extract_batch_device(orbhip_extractor* e, const uint8_t* d_imgs, int batch, int rows, int cols,
+                                ptrdiff_t row_stride, ptrdiff_t frame_stride, OrbKeypoint* d_kp_out,
+                                uint8_t* d_desc_out, int cap, int* d_n_out) {
+    int rc = check_call(e, batch, rows, cols, cap);
+    if (rc) return rc;
+    if (batch == 0 || rows == 0 || cols == 0) return ORBHIP_OK;  // empty image: silent no-op
+    if (!d_imgs || !d_kp_out || !d_desc_out || !d_n_out) return orb_fail(ORBHIP_EINVAL, "null buffer");
+    if (row_stride < cols) return orb_fail(ORBHIP_EINVAL, "row stride %td < cols %d", row_stride, cols);
+    HIPCHK(hipSetDevice(e->device));
+    const int chunk = std::min(batch, e->max_batch);
+    if ((rc = set_size(e, rows, cols, chunk))) return rc;
+    e->prof_chunks = 0;
+    HIPCHK(hipEventRecord(e->ev0, e->stream));
+    for (int f0 = 0; f0 < batch; f0 += chunk) {
+        const int b = std::min(chunk, batch - f0);
+        rc = run_chunk(e, d_imgs + (long long)f0 * frame_stride, b, row_stride, frame_stride, d_kp_out + (long long)f0 * cap,
+                       d_desc_out + (long long)f0 * cap * 32, cap, d_n_out + f0);
+        if (rc) return rc;
+    }
+    HIPCHK(hipEventRecord(e->ev1, e->stream));
+    return ORBHIP_OK;
+}
+
+int orbhip_extractor_synchronize(orbhip_extractor* e) {
+    if (!e) return orb_fail(ORBHIP_EINVAL, "null extractor");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (hipEventElapsedTime(&e->last_ms, e->ev0, e->ev1) != hipSuccess) e->last_ms = 0.f;
+    if (e->profiling) {
+        const int nl = e->nlevels;
+        const int per_chunk[ORB_NSTAGES] = {1, nl - 1, nl, 1, 1, 1, nl, 1};
+        for (int s = 0; s < ORB_NSTAGES; s++) {
+            e->stage_ms[s] = 0.f;
+            e->stage_launches[s] = per_chunk[s] * e->prof_chunks;
+        }
+        for (int c = 0; c < e->prof_chunks; c++)
+            for (int s = 0; s < ORB_NSTAGES; s++) {
+                float ms = 0.f;
+                hipEvent_t* pev = &e->prof_ev[(size_t)c * (ORB_NSTAGES + 1)];
+                if (hipEventElapsedTime(&ms, pev[s], pev[s + 1]) == hipSuccess) e->stage_ms[s] += ms;
+            }
+    }
+    return check_device_error(e);
+}
+
+int orbhip_extractor_set_profiling(orbhip_extractor* e, int enable) {
+    if (!e) return orb_fail(ORBHIP_EINVAL, "null extractor");
+    e->profiling = enable != 0;
+    return ORBHIP_OK;
+}
+
+int orbhip_extractor_stage_times(orbhip_extractor* e, float* ms_out, int* launches_out) {
+    if (!e || !ms_out || !launches_out) return orb_fail(ORBHIP_EINVAL, "null argument");
+    for (int s = 0; s < ORB_NSTAGES; s++) {
+        ms_out[s] = e->stage_ms[s];
+        launches_out[s] = e->stage_launches[s];
+    }
+    return ORB_NSTAGES;
+}
+
+void* orbhip_extractor_stream(orbhip_extractor* e) { return e ? (void*)e->stream : nullptr; }
+float orbhip_last_elapsed_ms(orbhip_extractor* e) { return e ? e->last_ms : 0.f; }
+
+int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int batch, int rows, int cols, ptrdiff_t row_stride,
+                         ptrdiff_t frame_stride, OrbKeypoint* kp_out, uint8_t* desc_out, int cap, int* n_out) {
+    int rc = check_call(e, batch, rows, cols, cap);
+    if (rc) return rc;
+    if (batch == 0 || rows == 0 || cols == 0) return ORBHIP_OK;
+    if (!imgs || !kp_out || !desc_out || !n_out) return orb_fail(ORBHIP_EINVAL, "null buffer");
+    if (row_stride < cols) return orb_fail(ORBHIP_EINVAL, "row stride %td < cols %d", row_stride, cols);
+    HIPCHK(hipSetDevice(e->device));
+    const int chunk = std::min(batch, e->max_batch);
+    const size_t img_bytes = (size_t)rows * cols;
+    if ((rc = e->d_img.ensure(img_bytes * chunk))) return rc;
+    if ((rc = e->d_kp.ensure(sizeof(OrbKeypoint) * (size_t)cap * chunk))) return rc;
+    if ((rc = e->d_desc.ensure((size_t)32 * cap * chunk))) return rc;
+    if ((rc = e->d_n.ensure(sizeof(int) * (size_t)chunk))) return rc;
+    for (int f0 = 0; f0 < batch; f0 += chunk) {
+        const int b = std::min(chunk, batch - f0);
+        for (int f = 0; f < b; f++)
+            HIPCHK(hipMemcpy2DAsync(e->d_img.as<uint8_t>() + (size_t)f * img_bytes, cols,
+                                    imgs + (ptrdiff_t)(f0 + f) * frame_stride, row_stride, cols, rows,
+                                    hipMemcpyHostToDevice, e->stream));
+        rc = orbhip_extract_batch_device(e, e->d_img.as<uint8_t>(), b, rows, cols, cols, (ptrdiff_t)img_bytes,
+                                         e->d_kp.as<OrbKeypoint>(), e->d_desc.as<uint8_t>(), cap, e->d_n.as<int>());
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(n_out + f0, e->d_n.p, sizeof(int) * b, hipMemcpyDeviceToHost, e->stream));
+        if ((rc = orbhip_extractor_synchronize(e))) return rc;
+        for (int f = 0; f < b; f++) {
+            const int n = n_out[f0 + f];
+            if (n > 0) {
+                HIPCHK(hipMemcpyAsync(kp_out + (size_t)(f0 + f) * cap, e->d_kp.as<OrbKeypoint>() + (size_t)f * cap,
+                                      sizeof(OrbKeypoint) * n, hipMemcpyDeviceToHost, e->stream));
+                HIPCHK(hipMemcpyAsync(desc_out + (size_t)(f0 + f) * cap * 32, e->d_desc.as<uint8_t>() + (size_t)f * cap * 32,
+                                      (size_t)32 * n, hipMemcpyDeviceToHost, e->stream));
+            }
+        }
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    return ORBHIP_OK;
+}
+
+int orbhip_extract(orbhip_extractor* e, const uint8_t* img, int rows, int cols, ptrdiff_t row_stride, OrbKeypoint* kp_out,
+                   uint8_t* desc_out, int cap, int* n_out) {
+    return orbhip_extract_batch(e, img, 1, rows, cols, row_stride, 0, kp_out, desc_out, cap, n_out);
+}
+
+int orbhip_level_geometry(const orbhip_extractor* e, int level, int32_t* out8) {
+    if (!e || !out8 || level < 0 || level >= e->nlevels) return ORBHIP_EINVAL;
+    const LevelGeom& L = e->hg.lv[level];
+    out8[0] = L.w; out8[1] = L.h; out8[2] = L.cols; out8[3] = L.rows;
+    out8[4] = L.cellW; out8[5] = L.cellH; out8[6] = L.nfeaturesCell; out8[7] = L.quota;
+    return ORBHIP_OK;
+}
+
+int orbhip_debug_get(orbhip_extractor* e, int stage, int frame, int level, void* buf, size_t buf_bytes) {
+    if (!e || !buf || level < 0 || level >= e->nlevels || frame < 0 || frame >= e->last_batch)
+        return orb_fail(ORBHIP_EINVAL, "bad tap request");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const GeomDev& g = e->hg;
+    const LevelGeom& L = g.lv[level];
+    if (stage >= 0 && stage <= 2) {
+        const int pw = L.w + 2 * ORB_EDGE;
+        if (buf_bytes < (size_t)pw * L.ph) return orb_fail(ORBHIP_ECAP, "tap buffer too small");
+        const DeviceBuf& src = stage == 0 ? e->d_pyr : stage == 1 ? e->d_blur : e->d_score;
+        HIPCHK(hipMemcpy2D(buf, pw, src.as<uint8_t>() + (size_t)frame * g.frame_bytes + L.plane_off, L.stride, pw, L.ph,
+                           hipMemcpyDeviceToHost));
+        return pw * L.ph;
+    }
+    if (stage == 3 || stage == 4) {
+        if (buf_bytes < sizeof(int) * (size_t)L.nCells) return orb_fail(ORBHIP_ECAP, "tap buffer too small");
+        const DeviceBuf& src = stage == 3 ? e->d_ntotal : e->d_nretain;
+        HIPCHK(hipMemcpy(buf, src.as<int>() + (size_t)frame * g.cells_per_frame + L.cell_base, sizeof(int) * L.nCells,
+                         hipMemcpyDeviceToHost));
+        return L.nCells;
+    }
+    if (stage == 5) {
+        int count = 0;
+        HIPCHK(hipMemcpy(&count, e->d_lvlcount.as<int>() + (size_t)frame * g.nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+        if (buf_bytes < sizeof(int) * 3 * (size_t)count) return orb_fail(ORBHIP_ECAP, "tap buffer too small");
+        std::vector<uint32_t> keys(count);
+        if (count)
+            HIPCHK(hipMemcpy(keys.data(), e->d_lvl.as<uint32_t>() + (size_t)frame * g.lvl_per_frame + L.lvl_off,
+                             sizeof(uint32_t) * count, hipMemcpyDeviceToHost));
+        int* o = (int*)buf;
+        for (int i = 0; i < count; i++) {
+            o[3 * i] = keys[i] & 0xfff;
+            o[3 * i + 1] = (keys[i] >> 12) & 0xfff;
+            o[3 * i + 2] = keys[i] >> 24;
+        }
+        return count;
+    }
+    if (stage == 6) {
+        std::vector<int> counts(L.nCells);
+        HIPCHK(hipMemcpy(counts.data(), e->d_ntotal.as<int>() + (size_t)frame * g.cells_per_frame + L.cell_base,
+                         sizeof(int) * L.nCells, hipMemcpyDeviceToHost));
+        size_t total = 0;
+        for (int c = 0; c < L.nCells; c++) total += counts[c];
+        if (buf_bytes < sizeof(int) * 3 * total) return orb_fail(ORBHIP_ECAP, "tap buffer too small");
+        int* o = (int*)buf;
+        std::vector<uint32_t> keys;
+        for (int c = 0; c < L.nCells; c++) {
+            const CellDesc& cd = e->hcells[L.cell_base + c];
+            keys.resize(counts[c]);
+            if (counts[c])
+                HIPCHK(hipMemcpy(keys.data(), e->d_cand.as<uint32_t>() + (size_t)frame * g.cand_per_frame + cd.cand_off,
+                                 sizeof(uint32_t) * counts[c], hipMemcpyDeviceToHost));
+            for (int i = 0; i < counts[c]; i++) {
+                *o++ = keys[i] & 0xfff;
+                *o++ = (keys[i] >> 12) & 0xfff;
+                *o++ = keys[i] >> 24;
+            }
+        }
+        return (int)total;
+    }
+    return orb_fail(ORBHIP_EINVAL, "unknown tap stage %d", stage);
+}
+
+// Device self-tests of arithmetic helpers (test instrumentation; declared in orbhip_test.h).
+int orbhip_selftest(int which, const void* in, int n, int aux, void* out) {
+    if (n <= 0) return ORBHIP_OK;
+    size_t in_bytes, out_bytes;
+    switch (which) {
+        case 0: in_bytes = 8ull * n; out_bytes = 4ull * n; break;   // atan2: (y, x) pairs -> degrees
+        case 1: in_bytes = 4ull * n; out_bytes = 8ull * n; break;   // angle -> (cos, sin)
+        case 2: in_bytes = 4ull * n; out_bytes = 4ull * n; break;   // keys, nth = aux -> permuted keys
+        case 3: in_bytes = 49ull * n; out_bytes = 4ull * n; break;  // 7x7 patches -> corner measure
+        default: return orb_fail(ORBHIP_EINVAL, "unknown selftest");
+    }
+    void *din = nullptr, *dout = nullptr;
+    HIPCHK(hipMalloc(&din, in_bytes));
+    if (hipMalloc(&dout, out_bytes) != hipSuccess) {
+        hipFree(din);
+        return orb_fail(ORBHIP_ENOMEM, "hipMalloc failed");
+    }
+    hipMemcpy(din, in, in_bytes, hipMemcpyHostToDevice);
+    switch (which) {
+        case 0: orbk::launch_test_atan2(0, (const float*)din, (float*)dout, n); break;
+        case 1: orbk::launch_test_sincos(0, (const float*)din, (float*)dout, n); break;
+        case 2:
+            orbk::launch_test_select(0, (uint32_t*)din, n, aux);
+            break;
+        case 3: orbk::launch_test_measure(0, (const uint8_t*)din, (int*)dout, n); break;
+    }
+    hipError_t err = hipDeviceSynchronize();
+    if (err == hipSuccess) err = hipMemcpy(out, which == 2 ? din : dout, out_bytes, hipMemcpyDeviceToHost);
+    hipFree(din);
+    hipFree(dout);
+    if (err != hipSuccess) return orb_fail(ORBHIP_EHIP, "selftest failed: %s", hipGetErrorString(err));
+    return ORBHIP_OK;
+}
+
+}  // extern "C"

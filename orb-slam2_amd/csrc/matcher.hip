@@ -1,0 +1,328 @@
+// Brute-force Hamming k=2 nearest-neighbour search over 256-bit ORB descriptors for gfx950:
+// the best / second-best ascending scan that every Search* method of the reference runs
+// (src/ORBmatcher.cc:461-485) with DescriptorDistance (:1805-1821) as the metric, evaluated
+// over the full train set of each (query set, train set) pair.
+//
+// Mapping: one lane owns one query (its 8 words live in VGPRs); the train rows are
+// wave-uniform, so they arrive through scalar loads and feed v_xor_b32 / v_bcnt_u32_b32 as SGPR
+// operands — no LDS, no MFMA (this is integer popcount work, not a dense contraction).
+// A candidate is folded into the running top-2 as one packed key (distance << 22 | row), which
+// makes "first index attaining the minimum" and "second order statistic with multiplicity" fall
+// out of two unsigned min/max operations in ascending row order.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cstring>
+#include <vector>
+
+#include "../../include/orbhip.h"
+#include "common.h"
+
+namespace {
+
+#define KNN_IDX_BITS 22
+#define KNN_IDX_MASK ((1u << KNN_IDX_BITS) - 1u)
+#define KNN_NONE 0xffffffffu
+
+__device__ __forceinline__ uint32_t ham8(const uint32_t q[8], const uint32_t* __restrict__ t) {
+    uint32_t d = __popc(q[0] ^ t[0]);
+    d += __popc(q[1] ^ t[1]);
+    d += __popc(q[2] ^ t[2]);
+    d += __popc(q[3] ^ t[3]);
+    d += __popc(q[4] ^ t[4]);
+    d += __popc(q[5] ^ t[5]);
+    d += __popc(q[6] ^ t[6]);
+    d += __popc(q[7] ^ t[7]);
+    return d;
+}
+
+// grid: (query blocks of 256, train chunks, pairs).  Each block scans rows [chunk*chunk_rows,
+// min(nt, (chunk+1)*chunk_rows)) and emits its two smallest keys per query.  With one chunk the
+// final (idx, d1, d2) are written directly.
+__global__ __launch_bounds__(256) void k_knn2(const uint32_t* __restrict__ q, int nq, long long q_pair_words,
+                                              const uint32_t* __restrict__ t, int nt, long long t_pair_words,
+                                              int chunk_rows, int nchunks, int idx_base, uint2* __restrict__ part,
+                                              int32_t* __restrict__ o_idx, int32_t* __restrict__ o_d1,
+                                              int32_t* __restrict__ o_d2) {
+    const int pair = blockIdx.z, chunk = blockIdx.y;
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    uint32_t qw[8];
+    {
+        const uint32_t* qp = q + (long long)pair * q_pair_words + (long long)min(qi, nq - 1) * 8;
+        const uint4 a = *(const uint4*)qp, b = *(const uint4*)(qp + 4);
+        qw[0] = a.x; qw[1] = a.y; qw[2] = a.z; qw[3] = a.w;
+        qw[4] = b.x; qw[5] = b.y; qw[6] = b.z; qw[7] = b.w;
+    }
+    const int j0 = chunk * chunk_rows;
+    const int rows = min(nt - j0, chunk_rows);
+    const uint32_t* __restrict__ tp = t + (long long)pair * t_pair_words + (long long)j0 * 8;
+    uint32_t best = KNN_NONE, best2 = KNN_NONE;
+    int j = 0;
+    for (; j + 4 <= rows; j += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t key = (ham8(qw, tp + (long long)(j + u) * 8) << KNN_IDX_BITS) | (uint32_t)(j + u);
+            best2 = min(best2, max(best, key));
+            best = min(best, key);
+        }
+    }
+    for (; j < rows; j++) {
+        const uint32_t key = (ham8(qw, tp + (long long)j * 8) << KNN_IDX_BITS) | (uint32_t)j;
+        best2 = min(best2, max(best, key));
+        best = min(best, key);
+    }
+    if (qi >= nq) return;
+    if (nchunks == 1) {
+        const long long o = (long long)pair * nq + qi;
+        o_idx[o] = best == KNN_NONE ? -1 : (int)(best & KNN_IDX_MASK) + idx_base;
+        o_d1[o] = best == KNN_NONE ? INT_MAX : (int)(best >> KNN_IDX_BITS);
+        o_d2[o] = best2 == KNN_NONE ? INT_MAX : (int)(best2 >> KNN_IDX_BITS);
+    } else {
+        part[((long long)pair * nchunks + chunk) * nq + qi] = make_uint2(best, best2);
+    }
+}
+
+// Chunks are index-contiguous and visited in ascending order, so folding each chunk's two
+// smallest distances with the reference's update rule reproduces the serial scan.
+__global__ __launch_bounds__(256) void k_knn2_fold(const uint2* __restrict__ part, int nq, int nchunks, int chunk_rows,
+                                                   int idx_base, int32_t* __restrict__ o_idx, int32_t* __restrict__ o_d1,
+                                                   int32_t* __restrict__ o_d2) {
+    const int pair = blockIdx.y;
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    int best = INT_MAX, best2 = INT_MAX, idx = -1;
+    for (int c = 0; c < nchunks; c++) {
+        const uint2 p = part[((long long)pair * nchunks + c) * nq + qi];
+        if (p.x == KNN_NONE) continue;
+        const int d1 = (int)(p.x >> KNN_IDX_BITS);
+        const int d2 = p.y == KNN_NONE ? INT_MAX : (int)(p.y >> KNN_IDX_BITS);
+        if (d1 < best) {
+            best2 = best;
+            best = d1;
+            idx = c * chunk_rows + (int)(p.x & KNN_IDX_MASK) + idx_base;
+        } else if (d1 < best2) {
+            best2 = d1;
+        }
+        if (d2 < best2) best2 = d2;
+    }
+    const long long o = (long long)pair * nq + qi;
+    o_idx[o] = idx;
+    o_d1[o] = best;
+    o_d2[o] = best2;
+}
+
+// Merge of per-shard (idx, d1, d2) triples of index-contiguous shards, ascending shard order.
+__global__ __launch_bounds__(256) void k_knn2_merge(const int32_t* __restrict__ parts, int nshards, int nq,
+                                                    int32_t* __restrict__ o_idx, int32_t* __restrict__ o_d1,
+                                                    int32_t* __restrict__ o_d2) {
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    int best = INT_MAX, best2 = INT_MAX, idx = -1;
+    for (int s = 0; s < nshards; s++) {
+        const int32_t* p = parts + (long long)s * 3 * nq;
+        const int i = p[qi], d1 = p[nq + qi], d2 = p[2 * nq + qi];
+        if (i < 0) continue;
+        if (d1 < best) {
+            best2 = best;
+            best = d1;
+            idx = i;
+        } else if (d1 < best2) {
+            best2 = d1;
+        }
+        if (d2 < best2) best2 = d2;
+    }
+    o_idx[qi] = idx;
+    o_d1[qi] = best;
+    o_d2[qi] = best2;
+}
+
+// src/ORBmatcher.cc:237 ((float)d1 < r*(float)d2), :487 (d1 <= d2*r, evaluated in float), with
+// the distance gate d1 <= th.  One multiply and one compare: nothing to contract.
+__global__ __launch_bounds__(256) void k_ratio(const int32_t* __restrict__ d1, const int32_t* __restrict__ d2, int n,
+                                               float ratio, int form, int th, uint8_t* __restrict__ accept) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int a = d1[i], b = d2[i];
+    bool ok;
+    if (form == 0) ok = (float)a < __fmul_rn(ratio, (float)b);
+    else ok = (float)a <= __fmul_rn((float)b, ratio);
+    accept[i] = (ok && a <= th) ? 1 : 0;
+}
+
+#define HIPCHK(call)                                                                         \
+    do {                                                                                     \
+        hipError_t err__ = (call);                                                           \
+        if (err__ != hipSuccess)                                                             \
+            return orb_fail(ORBHIP_EHIP, "%s failed: %s", #call, hipGetErrorString(err__)); \
+    } while (0)
+
+}  // namespace
+
+struct orbhip_matcher {
+    int device;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_ms = 0.f;
+    void* d_part = nullptr;
+    size_t part_bytes = 0;
+    void* d_stage = nullptr;  // staging of the host-pointer entry point
+    size_t stage_bytes = 0;
+    int sm_count = 256;
+};
+
+extern "C" {
+
+int orbhip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int orbhip_matcher_create(orbhip_matcher** out, int device) {
+    if (!out) return orb_fail(ORBHIP_EINVAL, "null out pointer");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return orb_fail(ORBHIP_ENODEV, "no HIP device");
+    if (device < 0 || device >= ndev) return orb_fail(ORBHIP_EINVAL, "device %d of %d", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    orbhip_matcher* m = new orbhip_matcher;
+    m->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) m->sm_count = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&m->ev0) != hipSuccess ||
+        hipEventCreate(&m->ev1) != hipSuccess) {
+        orbhip_matcher_destroy(m);
+        return orb_fail(ORBHIP_EHIP, "stream/event creation failed");
+    }
+    *out = m;
+    return ORBHIP_OK;
+}
+
+void orbhip_matcher_destroy(orbhip_matcher* m) {
+    if (!m) return;
+    hipSetDevice(m->device);
+    if (m->stream) hipStreamSynchronize(m->stream);
+    if (m->d_part) hipFree(m->d_part);
+    if (m->d_stage) hipFree(m->d_stage);
+    if (m->ev0) hipEventDestroy(m->ev0);
+    if (m->ev1) hipEventDestroy(m->ev1);
+    if (m->stream) hipStreamDestroy(m->stream);
+    delete m;
+}
+
+int orbhip_matcher_synchronize(orbhip_matcher* m) {
+    if (!m) return orb_fail(ORBHIP_EINVAL, "null matcher");
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (hipEventElapsedTime(&m->last_ms, m->ev0, m->ev1) != hipSuccess) m->last_ms = 0.f;
+    return ORBHIP_OK;
+}
+
+void* orbhip_matcher_stream(orbhip_matcher* m) { return m ? (void*)m->stream : nullptr; }
+float orbhip_matcher_last_elapsed_ms(orbhip_matcher* m) { return m ? m->last_ms : 0.f; }
+
+int orbhip_knn2_device(orbhip_matcher* m, const uint8_t* d_q, int nq, ptrdiff_t q_pair_stride, const uint8_t* d_t, int nt,
+                       ptrdiff_t t_pair_stride, int npairs, int idx_base, int32_t* d_idx, int32_t* d_d1, int32_t* d_d2) {
+    if (!m) return orb_fail(ORBHIP_EINVAL, "null matcher");
+    if (nq < 0 || nt < 0 || npairs < 0) return orb_fail(ORBHIP_EINVAL, "negative size");
+    if (nq == 0 || npairs == 0) return ORBHIP_OK;
+    if (!d_q || !d_idx || !d_d1 || !d_d2 || (nt > 0 && !d_t)) return orb_fail(ORBHIP_EINVAL, "null buffer");
+    if (((uintptr_t)d_q & 15) || ((uintptr_t)d_t & 3) || (q_pair_stride & 15) || (t_pair_stride & 3))
+        return orb_fail(ORBHIP_EINVAL, "descriptor buffers must be 16-byte (queries) / 4-byte (train) aligned");
+    if (npairs > 65535) return orb_fail(ORBHIP_EINVAL, "more than 65535 pairs in one call");
+    HIPCHK(hipSetDevice(m->device));
+    const int qblocks = (nq + 255) / 256;
+    // enough workgroups to fill the chip several times over; chunks never exceed the key's index field
+    const long long want = 8LL * m->sm_count;
+    int nchunks = (int)std::max<long long>(1, std::min<long long>((want + (long long)qblocks * npairs - 1) / ((long long)qblocks * npairs),
+                                                                    (nt + 511) / 512));
+    int chunk_rows = nt > 0 ? (nt + nchunks - 1) / nchunks : 1;
+    if (chunk_rows > (int)KNN_IDX_MASK) {
+        chunk_rows = KNN_IDX_MASK;
+        nchunks = (nt + chunk_rows - 1) / chunk_rows;
+    }
+    nchunks = nt > 0 ? (nt + chunk_rows - 1) / chunk_rows : 1;
+    if (nchunks > 65535) return orb_fail(ORBHIP_EINVAL, "train set too large");
+    if (nchunks > 1) {
+        const size_t need = (size_t)npairs * nchunks * nq * sizeof(uint2);
+        if (need > m->part_bytes) {
+            HIPCHK(hipStreamSynchronize(m->stream));
+            if (m->d_part) hipFree(m->d_part);
+            m->d_part = nullptr;
+            m->part_bytes = 0;
+            if (hipMalloc(&m->d_part, need) != hipSuccess) return orb_fail(ORBHIP_ENOMEM, "hipMalloc of %zu bytes failed", need);
+            m->part_bytes = need;
+        }
+    }
+    HIPCHK(hipEventRecord(m->ev0, m->stream));
+    hipLaunchKernelGGL(k_knn2, dim3(qblocks, nchunks, npairs), dim3(256), 0, m->stream, (const uint32_t*)d_q, nq,
+                       (long long)(q_pair_stride / 4), (const uint32_t*)d_t, nt, (long long)(t_pair_stride / 4), chunk_rows,
+                       nchunks, idx_base, (uint2*)m->d_part, d_idx, d_d1, d_d2);
+    if (nchunks > 1)
+        hipLaunchKernelGGL(k_knn2_fold, dim3(qblocks, npairs), dim3(256), 0, m->stream, (const uint2*)m->d_part, nq, nchunks,
+                           chunk_rows, idx_base, d_idx, d_d1, d_d2);
+    HIPCHK(hipEventRecord(m->ev1, m->stream));
+    HIPCHK(hipGetLastError());
+    return ORBHIP_OK;
+}
+
+int orbhip_knn2(orbhip_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int nt, int npairs, int32_t* idx, int32_t* d1,
+                int32_t* d2) {
+    if (!m) return orb_fail(ORBHIP_EINVAL, "null matcher");
+    if (nq < 0 || nt < 0 || npairs < 0) return orb_fail(ORBHIP_EINVAL, "negative size");
+    if (nq == 0 || npairs == 0) return ORBHIP_OK;
+    if (!q || !idx || !d1 || !d2 || (nt > 0 && !t)) return orb_fail(ORBHIP_EINVAL, "null buffer");
+    HIPCHK(hipSetDevice(m->device));
+    const size_t qb = (size_t)npairs * nq * 32, tb = (size_t)npairs * nt * 32, ob = (size_t)npairs * nq * 4;
+    const size_t qb_al = (qb + 255) & ~(size_t)255, tb_al = (tb + 255) & ~(size_t)255, ob_al = (ob + 255) & ~(size_t)255;
+    const size_t need = qb_al + tb_al + 3 * ob_al + 256;
+    if (need > m->stage_bytes) {
+        HIPCHK(hipStreamSynchronize(m->stream));
+        if (m->d_stage) hipFree(m->d_stage);
+        m->d_stage = nullptr;
+        m->stage_bytes = 0;
+        if (hipMalloc(&m->d_stage, need) != hipSuccess) return orb_fail(ORBHIP_ENOMEM, "hipMalloc of %zu bytes failed", need);
+        m->stage_bytes = need;
+    }
+    uint8_t* base = (uint8_t*)m->d_stage;
+    uint8_t* dq = base;
+    uint8_t* dt = base + qb_al;
+    int32_t* di = (int32_t*)(dt + tb_al);
+    int32_t* dd1 = (int32_t*)((uint8_t*)di + ob_al);
+    int32_t* dd2 = (int32_t*)((uint8_t*)dd1 + ob_al);
+    HIPCHK(hipMemcpyAsync(dq, q, qb, hipMemcpyHostToDevice, m->stream));
+    if (tb) HIPCHK(hipMemcpyAsync(dt, t, tb, hipMemcpyHostToDevice, m->stream));
+    int rc = orbhip_knn2_device(m, dq, nq, (ptrdiff_t)nq * 32, dt, nt, (ptrdiff_t)nt * 32, npairs, 0, di, dd1, dd2);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(idx, di, ob, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(d1, dd1, ob, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(d2, dd2, ob, hipMemcpyDeviceToHost, m->stream));
+    return orbhip_matcher_synchronize(m);
+}
+
+int orbhip_knn2_merge_device(orbhip_matcher* m, const int32_t* d_parts, int nshards, int nq, int32_t* d_idx, int32_t* d_d1,
+                             int32_t* d_d2) {
+    if (!m) return orb_fail(ORBHIP_EINVAL, "null matcher");
+    if (nshards < 1 || nq < 0) return orb_fail(ORBHIP_EINVAL, "bad size");
+    if (nq == 0) return ORBHIP_OK;
+    if (!d_parts || !d_idx || !d_d1 || !d_d2) return orb_fail(ORBHIP_EINVAL, "null buffer");
+    HIPCHK(hipSetDevice(m->device));
+    hipLaunchKernelGGL(k_knn2_merge, dim3((nq + 255) / 256), dim3(256), 0, m->stream, d_parts, nshards, nq, d_idx, d_d1, d_d2);
+    HIPCHK(hipGetLastError());
+    return ORBHIP_OK;
+}
+
+int orbhip_ratio_test_device(orbhip_matcher* m, const int32_t* d_d1, const int32_t* d_d2, int n, float ratio, int form, int th,
+                             uint8_t* d_accept) {
+    if (!m) return orb_fail(ORBHIP_EINVAL, "null matcher");
+    if (n < 0 || (form != 0 && form != 1)) return orb_fail(ORBHIP_EINVAL, "bad argument");
+    if (n == 0) return ORBHIP_OK;
+    if (!d_d1 || !d_d2 || !d_accept) return orb_fail(ORBHIP_EINVAL, "null buffer");
+    HIPCHK(hipSetDevice(m->device));
+    hipLaunchKernelGGL(k_ratio, dim3((n + 255) / 256), dim3(256), 0, m->stream, d_d1, d_d2, n, ratio, form, th, d_accept);
+    HIPCHK(hipGetLastError());
+    return ORBHIP_OK;
+}
+
+}  // extern "C"

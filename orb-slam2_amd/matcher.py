@@ -1,0 +1,81 @@
+"""Host-side mirror of the accelerated part of ORB_SLAM::ORBmatcher (include/ORBmatcher.h:39-109):
+DescriptorDistance, the best/second-best scan with the ratio test, and the static thresholds.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+INT_MAX = 2147483647
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class ORBmatcher:
+    TH_HIGH = 100      # src/ORBmatcher.cc:42
+    TH_LOW = 20        # :44
+    HISTO_LENGTH = 30  # :45
+
+    def __init__(self, nnratio=0.6, checkOri=True, device=0):
+        self.mfNNratio = float(np.float32(nnratio))
+        self.mbCheckOrientation = bool(checkOri)
+        self._L = _lib.lib()
+        self._h = C.c_void_p()
+        _lib.check(self._L.orbhip_matcher_create(C.byref(self._h), device))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.orbhip_matcher_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def DescriptorDistance(a, b):
+        """static int DescriptorDistance(const cv::Mat&, const cv::Mat&), include/ORBmatcher.h:46."""
+        a = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1)
+        b = np.ascontiguousarray(b, dtype=np.uint8).reshape(-1)
+        assert a.size == 32 and b.size == 32
+        return _lib.lib().orbhip_hamming_distance(_p(a), _p(b))
+
+    def knn2(self, queries, train):
+        """queries [P, nq, 32] or [nq, 32]; train [P, nt, 32] or [nt, 32] (host arrays).
+        Returns (idx, d1, d2) int32 arrays of shape [P, nq] or [nq]."""
+        q = np.ascontiguousarray(queries, dtype=np.uint8)
+        t = np.ascontiguousarray(train, dtype=np.uint8)
+        single = q.ndim == 2
+        if single:
+            q, t = q[None], t[None]
+        assert q.shape[0] == t.shape[0] and q.shape[2] == 32 and t.shape[2] == 32
+        P, nq, nt = q.shape[0], q.shape[1], t.shape[1]
+        idx = np.full((P, nq), -1, np.int32)
+        d1 = np.full((P, nq), INT_MAX, np.int32)
+        d2 = np.full((P, nq), INT_MAX, np.int32)
+        _lib.check(self._L.orbhip_knn2(self._h, _p(q), nq, _p(t), nt, P, _p(idx), _p(d1), _p(d2)))
+        if single:
+            return idx[0], d1[0], d2[0]
+        return idx, d1, d2
+
+    def knn2_device(self, d_q, nq, q_pair_stride, d_t, nt, t_pair_stride, npairs, idx_base, d_idx, d_d1, d_d2):
+        _lib.check(self._L.orbhip_knn2_device(self._h, d_q, nq, q_pair_stride, d_t, nt, t_pair_stride, npairs, idx_base,
+                                              d_idx, d_d1, d_d2))
+
+    def merge_device(self, d_parts, nshards, nq, d_idx, d_d1, d_d2):
+        _lib.check(self._L.orbhip_knn2_merge_device(self._h, d_parts, nshards, nq, d_idx, d_d1, d_d2))
+
+    def ratio_test_device(self, d_d1, d_d2, n, form, th, d_accept, ratio=None):
+        r = self.mfNNratio if ratio is None else ratio
+        _lib.check(self._L.orbhip_ratio_test_device(self._h, d_d1, d_d2, n, r, form, th, d_accept))
+
+    def synchronize(self):
+        _lib.check(self._L.orbhip_matcher_synchronize(self._h))
+
+    def last_elapsed_ms(self):
+        return self._L.orbhip_matcher_last_elapsed_ms(self._h)

@@ -1,0 +1,142 @@
+// Host unit tests of the algorithm headers the device code is built from.
+//   host_units select            : orbsel::nth_element_desc vs std::nth_element, permutation-exact
+//   host_units trig <stride> [exhaustive]: orbtrig sin/cos vs the host libm over [0, 6.2832]
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <thread>
+#include <vector>
+
+#include "../../orb-slam2_amd/csrc/introselect.h"
+#include "../../orb-slam2_amd/csrc/sincos_port.h"
+
+struct KP { float response; int id; };
+struct Greater { bool operator()(const KP& a, const KP& b) const { return a.response > b.response; } };
+
+static int test_select() {
+    std::mt19937 rng(12345);
+    int bad = 0, cases = 0;
+    const int sizes[] = {1, 2, 3, 4, 5, 7, 8, 15, 16, 17, 31, 33, 64, 100, 129, 255, 480, 600, 1000, 2049, 5000};
+    for (int n : sizes)
+        for (int rep = 0; rep < 40; rep++) {
+            int mode = rep % 5;
+            std::vector<uint32_t> keys(n);
+            std::vector<KP> ref(n);
+            for (int i = 0; i < n; i++) {
+                int s;
+                switch (mode) {
+                    case 0: s = 7 + rng() % 4; break;             // extreme ties
+                    case 1: s = rng() % 255; break;               // spread
+                    case 2: s = i % 255; break;                   // ascending saw
+                    case 3: s = 254 - (i % 255); break;           // descending saw
+                    default: s = (rng() % 8 == 0) ? rng() % 255 : 20; break;  // mostly equal
+                }
+                keys[i] = ((uint32_t)s << 24) | (uint32_t)i;
+                ref[i].response = (float)s;
+                ref[i].id = i;
+            }
+            int ks[] = {1, n / 7, n / 2, n - 1, (int)(rng() % n)};
+            for (int k : ks) {
+                if (k < 0 || k >= n) continue;
+                std::vector<uint32_t> a = keys;
+                std::vector<KP> b = ref;
+                orbsel::nth_element_desc(a.data(), n, k);
+                std::nth_element(b.begin(), b.begin() + k, b.end(), Greater());
+                cases++;
+                for (int i = 0; i < n; i++)
+                    if ((int)(a[i] & 0xffffff) != b[i].id) { bad++; break; }
+            }
+        }
+    // adversarial: median-of-3 killer-like organ pipe to reach the heap fallback
+    for (int n : {64, 200, 1000, 4000}) {
+        std::vector<uint32_t> keys(n);
+        std::vector<KP> ref(n);
+        for (int i = 0; i < n; i++) {
+            int s = (i < n / 2) ? i % 250 : (n - i) % 250;
+            keys[i] = ((uint32_t)s << 24) | (uint32_t)i;
+            ref[i].response = (float)s; ref[i].id = i;
+        }
+        for (int k : {1, n / 3, n - 2}) {
+            std::vector<uint32_t> a = keys;
+            std::vector<KP> b = ref;
+            orbsel::nth_element_desc(a.data(), n, k);
+            std::nth_element(b.begin(), b.begin() + k, b.end(), Greater());
+            cases++;
+            for (int i = 0; i < n; i++)
+                if ((int)(a[i] & 0xffffff) != b[i].id) { bad++; break; }
+        }
+    }
+    // heap-select branch: same depth limit given to libstdc++'s internal __introselect
+    for (int n : {5, 9, 33, 100, 777, 3000})
+        for (int depth : {0, 1, 2, 3})
+            for (int rep = 0; rep < 10; rep++) {
+                std::vector<uint32_t> keys(n);
+                std::vector<KP> ref(n);
+                for (int i = 0; i < n; i++) {
+                    int s = (rep & 1) ? 7 + rng() % 6 : rng() % 255;
+                    keys[i] = ((uint32_t)s << 24) | (uint32_t)i;
+                    ref[i].response = (float)s; ref[i].id = i;
+                }
+                int k = rng() % n;
+                std::vector<uint32_t> a = keys;
+                std::vector<KP> b = ref;
+                orbsel::nth_element_desc(a.data(), n, k, depth);
+                std::__introselect(b.begin(), b.begin() + k, b.end(), depth, __gnu_cxx::__ops::__iter_comp_iter(Greater()));
+                cases++;
+                for (int i = 0; i < n; i++)
+                    if ((int)(a[i] & 0xffffff) != b[i].id) { bad++; break; }
+            }
+    printf("select: %d cases, %d mismatching permutations\n", cases, bad);
+    return bad;
+}
+
+template <bool FMA>
+static void trig_range(uint32_t lo, uint32_t hi, uint32_t stride, long* bad_sin, long* bad_cos) {
+    long bs = 0, bc = 0;
+    for (uint64_t u = lo; u < hi; u += stride) {
+        float x;
+        uint32_t uu = (uint32_t)u;
+        memcpy(&x, &uu, 4);
+        float s = orbtrig::sin_f<FMA>(x), c = orbtrig::cos_f<FMA>(x);
+        float rs = sinf(x), rc = cosf(x);
+        if (memcmp(&s, &rs, 4)) bs++;
+        if (memcmp(&c, &rc, 4)) bc++;
+    }
+    *bad_sin = bs;
+    *bad_cos = bc;
+}
+
+template <bool FMA>
+static long test_trig(uint32_t stride) {
+    float top = 6.2832f;
+    uint32_t hi;
+    memcpy(&hi, &top, 4);
+    const int T = 8;
+    std::vector<std::thread> th;
+    long bs[T], bc[T];
+    uint32_t chunk = hi / T + 1;
+    for (int t = 0; t < T; t++) {
+        uint32_t a = t * chunk, b = std::min<uint64_t>((uint64_t)(t + 1) * chunk, (uint64_t)hi + 1);
+        th.emplace_back(trig_range<FMA>, a, b, stride, &bs[t], &bc[t]);
+    }
+    long S = 0, Cc = 0;
+    for (int t = 0; t < T; t++) { th[t].join(); S += bs[t]; Cc += bc[t]; }
+    printf("trig fma=%d stride=%u: sin mismatches %ld, cos mismatches %ld\n", (int)FMA, stride, S, Cc);
+    return S + Cc;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) return 2;
+    if (!strcmp(argv[1], "select")) return test_select() ? 1 : 0;
+    if (!strcmp(argv[1], "trig")) {
+        uint32_t stride = argc > 2 ? (uint32_t)atoi(argv[2]) : 97;
+        long a = test_trig<false>(stride);
+        long b = test_trig<true>(stride);
+        // exit 0 if the plain (non-fused) variant is exact, 3 if only the fused one is
+        return a == 0 ? 0 : (b == 0 ? 3 : 1);
+    }
+    return 2;
+}

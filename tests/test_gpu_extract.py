@@ -1,0 +1,163 @@
+"""Parity of the HIP extractor against the CPU oracle, through the C ABI (ctypes), stage by stage
+and end to end.  Bar: keypoint coordinates, octaves, responses, sizes and descriptor bytes
+bit-exact; angles bit-exact as well (the north-star tolerance is 1e-4 degrees; the device uses the
+same fp32 polynomial without contraction, so equality is what is asserted and the tolerance is
+only reported)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # (width, height, nfeatures, nlevels, fastTh, frame_idx)
+    (640, 480, 1000, 8, 20, 0),
+    (640, 480, 1000, 8, 20, 7),
+    (320, 240, 500, 6, 20, 1),
+    (1280, 720, 2000, 8, 20, 2),
+    (752, 480, 1500, 8, 12, 3),
+    (500, 375, 800, 5, 30, 4),
+]
+
+
+def _make(orb, orbref, w, h, nf, nl, th, **kw):
+    dev = orb.ORBextractor(nf, 1.2, nl, 1, th, device=0, max_width=w, max_height=h, max_batch=kw.get("max_batch", 1))
+    ref = orbref.RefExtractor(nf, 1.2, nl, 1, th)
+    return dev, ref
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_tables_and_geometry(orb, orbref, synth, case):
+    w, h, nf, nl, th, fi = case
+    dev, ref = _make(orb, orbref, w, h, nf, nl, th)
+    for which in range(5):
+        assert np.array_equal(dev.table(which), ref.table(which)), which
+    assert dev.GetLevels() == ref.GetLevels()
+    assert dev.GetScaleFactor() == ref.GetScaleFactor()
+    ref(synth.synth_image(w, h, fi))
+    for l in range(nl):
+        g = dev.level_geometry(l)
+        rg = ref.level_grid(l)
+        assert (g["w"], g["h"]) == ref.level_size(l)
+        for k in ("cols", "rows", "cellW", "cellH", "nfeaturesCell"):
+            assert g[k] == rg[k], (l, k)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_stages(orb, orbref, synth, case):
+    w, h, nf, nl, th, fi = case
+    dev, ref = _make(orb, orbref, w, h, nf, nl, th)
+    img = synth.synth_image(w, h, fi)
+    rkp, rdesc = ref(img)
+    dkp, ddesc = dev(img)
+    for l in range(nl):
+        rp = ref.plane(l, blurred=False)
+        dp = dev.tap_plane(0, 0, l)
+        assert np.array_equal(rp, dp), "pyramid level %d: %d px differ" % (l, int((rp != dp).sum()))
+    for l in range(nl):
+        counts, cand = ref.level_candidates(l)
+        dcounts = dev.tap_cells(3, 0, l)
+        assert np.array_equal(counts, dcounts), "level %d candidate counts" % l
+        dcand = dev.tap_candidates(0, l)
+        # after selection a cell's device list is a permutation of its raster-ordered candidates
+        o = 0
+        for c, n in enumerate(counts):
+            a = sorted(map(tuple, cand[o:o + n]))
+            b = sorted(map(tuple, dcand[o:o + n]))
+            assert a == b, "level %d cell %d candidates" % (l, c)
+            o += n
+        assert np.array_equal(ref.level_retain(l), dev.tap_cells(4, 0, l)), "level %d nToRetain" % l
+        assert np.array_equal(ref.level_keypoints(l), dev.tap_level_keypoints(0, l)), "level %d selection" % l
+    for l in range(nl):
+        rb = ref.plane(l, blurred=True)
+        if rb is None:
+            continue
+        db = dev.tap_plane(1, 0, l)
+        assert np.array_equal(rb, db), "blurred level %d: %d px differ" % (l, int((rb != db).sum()))
+    assert len(rkp) == len(dkp)
+
+
+def _assert_same(rkp, rdesc, dkp, ddesc):
+    assert len(rkp) == len(dkp)
+    for f in ("x", "y", "size", "response", "octave", "class_id"):
+        assert np.array_equal(rkp[f], dkp[f]), f
+    dang = np.abs(rkp["angle"].astype(np.float64) - dkp["angle"].astype(np.float64))
+    assert dang.max(initial=0.0) <= 1e-4, "orientation differs by %g deg" % dang.max()
+    assert np.array_equal(rkp["angle"].view(np.uint32), dkp["angle"].view(np.uint32))
+    flips = int(np.unpackbits(rdesc ^ ddesc).sum())
+    assert flips == 0, "%d descriptor bits differ" % flips
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_end_to_end(orb, orbref, synth, case):
+    w, h, nf, nl, th, fi = case
+    dev, ref = _make(orb, orbref, w, h, nf, nl, th)
+    img = synth.synth_image(w, h, fi)
+    rkp, rdesc = ref(img)
+    dkp, ddesc = dev(img)
+    _assert_same(rkp, rdesc, dkp, ddesc)
+    assert len(rkp) > 0
+
+
+def test_batch_matches_single(orb, orbref, synth):
+    w, h, nf = 640, 480, 1000
+    dev, ref = _make(orb, orbref, w, h, nf, 8, 20, max_batch=4)
+    imgs = synth.synth_batch(w, h, 6, first_idx=20)  # 6 frames through chunks of 4
+    out = dev.extract_batch(imgs)
+    assert len(out) == 6
+    for f in range(6):
+        rkp, rdesc = ref(imgs[f])
+        _assert_same(rkp, rdesc, out[f][0], out[f][1])
+
+
+def test_strided_input_and_reuse(orb, orbref, synth):
+    """A view with a row stride larger than its width, then a different size on the same handle."""
+    dev, ref = _make(orb, orbref, 640, 480, 1000, 8, 20)
+    big = synth.synth_image(800, 600, 30)
+    view = big[50:530, 100:740]
+    assert view.strides[0] == 800
+    rkp, rdesc = ref(np.ascontiguousarray(view))
+    dkp, ddesc = dev(view)
+    _assert_same(rkp, rdesc, dkp, ddesc)
+    img2 = synth.synth_image(512, 384, 31)
+    rkp, rdesc = ref(img2)
+    dkp, ddesc = dev(img2)
+    _assert_same(rkp, rdesc, dkp, ddesc)
+
+
+def test_sparse_image_uses_threshold_7(orb, orbref):
+    """Mostly flat frame with a few weak corners: cells fall back to FAST threshold 7
+    (src/ORBextractor.cc:609-614) and many cells stay empty (quota redistribution)."""
+    rng = np.random.default_rng(5)
+    img = np.full((480, 640), 100, np.uint8)
+    for _ in range(60):
+        x, y = int(rng.integers(30, 600)), int(rng.integers(30, 440))
+        img[y:y + 9, x:x + 9] = 100 + int(rng.integers(9, 19))
+    for _ in range(25):
+        x, y = int(rng.integers(30, 600)), int(rng.integers(30, 440))
+        img[y:y + 12, x:x + 12] = 200
+    dev, ref = _make(orb, orbref, 640, 480, 1000, 8, 20)
+    rkp, rdesc = ref(img)
+    dkp, ddesc = dev(img)
+    assert len(rkp) > 0
+    assert (rkp["response"] < 20).any()
+    _assert_same(rkp, rdesc, dkp, ddesc)
+
+
+def test_blank_image_gives_no_keypoints(orb, orbref):
+    img = np.full((480, 640), 77, np.uint8)
+    dev, ref = _make(orb, orbref, 640, 480, 1000, 8, 20)
+    rkp, _ = ref(img)
+    dkp, ddesc = dev(img)
+    assert len(rkp) == 0 and len(dkp) == 0 and ddesc.shape == (0, 32)
+
+
+def test_empty_image_and_errors(orb):
+    dev = orb.ORBextractor(1000, 1.2, 8, 1, 20, device=0, max_width=640, max_height=480)
+    assert dev(np.zeros((0, 0), np.uint8)) == (None, None)
+    with pytest.raises(AssertionError):
+        dev(np.zeros((480, 640, 3), np.uint8))
+    with pytest.raises(orb.OrbhipError) as ei:
+        dev(np.zeros((40, 40), np.uint8))  # no interior inside the 16-px border at the top levels
+    assert ei.value.code == -5
+    with pytest.raises(orb.OrbhipError):
+        orb.ORBextractor(0, 1.2, 8, 1, 20)

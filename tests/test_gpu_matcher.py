@@ -1,0 +1,101 @@
+"""Parity of the HIP Hamming kNN (k=2) against the oracle's scalar scan, through the C ABI.
+Bar: idx, d1, d2 bit-exact (integer work)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+INT_MAX = 2147483647
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (1, 2), (7, 1), (5, 3), (256, 255), (257, 513), (2000, 2000), (300, 5000)])
+def test_knn2_single_pair(orb, orbref, synth, nq, nt):
+    q, t = synth.synth_descriptors(nq, nt, seed=nq * 7919 + nt)
+    m = orb.ORBmatcher(0.6, True)
+    idx, d1, d2 = m.knn2(q, t)
+    ridx, rd1, rd2 = orbref.knn2(q, t)
+    assert np.array_equal(idx, ridx)
+    assert np.array_equal(d1, rd1)
+    assert np.array_equal(d2, rd2)
+
+
+def test_knn2_empty_train(orb):
+    m = orb.ORBmatcher()
+    q = np.zeros((5, 32), np.uint8)
+    idx, d1, d2 = m.knn2(q, np.zeros((0, 32), np.uint8))
+    assert (idx == -1).all() and (d1 == INT_MAX).all() and (d2 == INT_MAX).all()
+
+
+def test_knn2_ties_take_first_index(orb, orbref):
+    """All train rows identical: best = row 0, second = the same distance (multiplicity)."""
+    q = np.random.default_rng(0).integers(0, 256, (70, 32), dtype=np.uint8)
+    t = np.tile(np.arange(32, dtype=np.uint8), (900, 1))
+    m = orb.ORBmatcher()
+    idx, d1, d2 = m.knn2(q, t)
+    assert (idx == 0).all() and np.array_equal(d1, d2)
+    ridx, rd1, rd2 = orbref.knn2(q, t)
+    assert np.array_equal(idx, ridx) and np.array_equal(d1, rd1) and np.array_equal(d2, rd2)
+
+
+def test_knn2_batched_pairs(orb, orbref, synth):
+    P, nq, nt = 9, 300, 400
+    qs, ts = zip(*[synth.synth_descriptors(nq, nt, seed=100 + p) for p in range(P)])
+    q, t = np.stack(qs), np.stack(ts)
+    m = orb.ORBmatcher()
+    idx, d1, d2 = m.knn2(q, t)
+    for p in range(P):
+        ridx, rd1, rd2 = orbref.knn2(q[p], t[p])
+        assert np.array_equal(idx[p], ridx) and np.array_equal(d1[p], rd1) and np.array_equal(d2[p], rd2)
+
+
+def test_knn2_chunked_large_train(orb, orbref, synth):
+    """Few queries against many rows: the train set is split over workgroups and folded."""
+    q, t = synth.synth_descriptors(64, 200000, seed=3)
+    t[150000:150050] = t[10]  # duplicates far apart: the first index must win
+    q[0] = t[10]
+    m = orb.ORBmatcher()
+    idx, d1, d2 = m.knn2(q, t)
+    ridx, rd1, rd2 = orbref.knn2(q, t)
+    assert np.array_equal(idx, ridx) and np.array_equal(d1, rd1) and np.array_equal(d2, rd2)
+    assert idx[0] == 10 and d1[0] == 0 and d2[0] == 0
+
+
+def test_sharded_merge_and_ratio(orb, orbref, synth):
+    """Index-contiguous shards merged on the device equal the unsharded scan; ratio test forms."""
+    import torch
+    nq, nt, G = 500, 4096, 4
+    q, t = synth.synth_descriptors(nq, nt, seed=11)
+    ridx, rd1, rd2 = orbref.knn2(q, t)
+    m = orb.ORBmatcher(0.6)
+    dq = torch.from_numpy(q).cuda()
+    dt = torch.from_numpy(t).cuda()
+    parts = torch.empty((G, 3, nq), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    sz = nt // G
+    for g in range(G):
+        m.knn2_device(dq.data_ptr(), nq, nq * 32, dt.data_ptr() + g * sz * 32, sz, sz * 32, 1, g * sz,
+                      parts[g, 0].data_ptr(), parts[g, 1].data_ptr(), parts[g, 2].data_ptr())
+    out = torch.empty((3, nq), dtype=torch.int32, device="cuda")
+    acc = torch.empty((2, nq), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    m.merge_device(parts.data_ptr(), G, nq, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr())
+    m.ratio_test_device(out[1].data_ptr(), out[2].data_ptr(), nq, 0, 100, acc[0].data_ptr())
+    m.ratio_test_device(out[1].data_ptr(), out[2].data_ptr(), nq, 1, 20, acc[1].data_ptr())
+    m.synchronize()
+    o = out.cpu().numpy()
+    assert np.array_equal(o[0], ridx) and np.array_equal(o[1], rd1) and np.array_equal(o[2], rd2)
+    L = orbref.lib()
+    a0 = np.array([L.orbref_ratio_accept(int(a), int(b), 0.6, 0) and a <= 100 for a, b in zip(rd1, rd2)], np.uint8)
+    a1 = np.array([L.orbref_ratio_accept(int(a), int(b), 0.6, 1) and a <= 20 for a, b in zip(rd1, rd2)], np.uint8)
+    acc = acc.cpu().numpy()
+    assert np.array_equal(acc[0], a0) and np.array_equal(acc[1], a1)
+    assert a0.sum() > 0
+
+
+def test_descriptor_distance_host(orb, orbref):
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        a = rng.integers(0, 256, 32, dtype=np.uint8)
+        b = rng.integers(0, 256, 32, dtype=np.uint8)
+        assert orb.ORBmatcher.DescriptorDistance(a, b) == orbref.hamming(a, b)
