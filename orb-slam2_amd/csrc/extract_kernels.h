@@ -19,6 +19,10 @@ void launch_score(hipStream_t st, const GeomDev& hg, int batch, int level, const
                   const GeomDev* dg);
 void launch_nms(hipStream_t st, const GeomDev& hg, int batch, int max_cell_h, const uint8_t* score, const GeomDev* dg,
                 const CellDesc* cells, uint32_t* cand, int* n_total, int* err);
+// Fused per-cell FAST (fast_cell.hip); usable when every cell satisfies fast_cell_supported.
+bool fast_cell_supported(int cw, int ch);
+void launch_fast_cell(hipStream_t st, const GeomDev& hg, int batch, int max_cw, int max_ch, const uint8_t* pyr,
+                      const GeomDev* dg, const CellDesc* cells, uint32_t* cand, int* n_total, int* err);
 void launch_select(hipStream_t st, const GeomDev& hg, int batch, const GeomDev* dg, const CellDesc* cells,
                    uint32_t* cand, const int* n_total, int* n_retain, uint32_t* lvl_list, int* lvl_count, int* err);
 void launch_orient(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* pyr, const GeomDev* dg,

@@ -9,6 +9,7 @@
 #include <stdint.h>
 
 #include "extract_kernels.h"
+#include "fast_measure.h"
 #include "introselect.h"
 #include "sincos_port.h"
 
@@ -50,82 +51,70 @@ __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ imgs
 // Level l >= 1: resize(level l-1 ROI -> level l ROI, INTER_LINEAR) then copyMakeBorder
 // REFLECT_101 (src/ORBextractor.cc:800-807), fused: every padded pixel is computed from the
 // interior pixel it reflects to.  Coefficient tables hold OpenCV's 11-bit fixed-point weights.
+// One thread owns an aligned dword column (4 pixels) and walks RZ_ROWS rows: its four column
+// entries (source offset, weights) are loaded once, the row entries are wave-uniform, and the
+// horizontal interpolation of the lower source row is kept for the next output row, which usually
+// needs it as its upper row (the scale is < 2).
+#define RZ_ROWS 8
+
 __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, const GeomDev* __restrict__ g, int level,
                                                 const int* __restrict__ xofs, const uint32_t* __restrict__ xab,
                                                 const uint32_t* __restrict__ ysrc, const uint32_t* __restrict__ yab) {
     const LevelGeom& L = g->lv[level];
     const LevelGeom& P = g->lv[level - 1];
     const int dwx = blockIdx.x * 64 + threadIdx.x;
-    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int ybase = (blockIdx.y * 4 + threadIdx.y) * RZ_ROWS;
     const int f = blockIdx.z;
-    if (dwx * 4 >= L.stride || y >= L.ph) return;
+    if (dwx * 4 >= L.stride || ybase >= L.ph) return;
     uint8_t* frame = pyr + (long long)f * g->frame_bytes;
     const uint8_t* src = frame + P.plane_off + (long long)ORB_EDGE * P.stride + ORB_EDGE;
-    const int dy = reflect101(y - ORB_EDGE, L.h);
-    const uint32_t ys = ysrc[L.rz_y_off + dy], yb = yab[L.rz_y_off + dy];
-    const uint8_t* S0 = src + (long long)(ys & 0xffff) * P.stride;
-    const uint8_t* S1 = src + (long long)(ys >> 16) * P.stride;
-    const int b0 = yb & 0xffff, b1 = yb >> 16;
-    uint32_t out = 0;
+    uint8_t* dst = frame + L.plane_off + dwx * 4;
+    int sx[4], sx1[4], a0[4], a1[4];
+    uint32_t keep = 0;  // bytes of the dword that are inside the padded plane
 #pragma unroll
     for (int b = 0; b < 4; b++) {
         const int x = dwx * 4 + b;
-        uint32_t v = 0;
-        if (x < L.w + 2 * ORB_EDGE) {
-            const int dx = reflect101(x - ORB_EDGE, L.w);
-            const int sx = xofs[L.rz_x_off + dx];
-            const int sx1 = min(sx + 1, P.w - 1);
-            const uint32_t xa = xab[L.rz_x_off + dx];
-            const int a0 = xa & 0xffff, a1 = xa >> 16;
-            const int t0 = S0[sx] * a0 + S0[sx1] * a1;
-            const int t1 = S1[sx] * a0 + S1[sx1] * a1;
-            v = (uint32_t)((((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2) & 0xff;
-        }
-        out |= v << (8 * b);
+        if (x < L.w + 2 * ORB_EDGE) keep |= 0xffu << (8 * b);
+        const int dx = reflect101(min(x, L.w + 2 * ORB_EDGE - 1) - ORB_EDGE, L.w);
+        sx[b] = xofs[L.rz_x_off + dx];
+        sx1[b] = min(sx[b] + 1, P.w - 1);
+        const uint32_t xa = xab[L.rz_x_off + dx];
+        a0[b] = xa & 0xffff;
+        a1[b] = xa >> 16;
     }
-    *(uint32_t*)(frame + L.plane_off + (long long)y * L.stride + dwx * 4) = out;
+    int cached_row = -1;
+    int ct[4] = {0, 0, 0, 0};
+    const int yend = min(ybase + RZ_ROWS, L.ph);
+    for (int y = ybase; y < yend; y++) {
+        const int dy = reflect101(y - ORB_EDGE, L.h);
+        const uint32_t ys = ysrc[L.rz_y_off + dy], yb = yab[L.rz_y_off + dy];
+        const int sy0 = ys & 0xffff, sy1 = ys >> 16;
+        const int b0 = yb & 0xffff, b1 = yb >> 16;
+        const uint8_t* S1 = src + (long long)sy1 * P.stride;
+        int t0[4], t1[4];
+        if (sy0 == cached_row) {
+#pragma unroll
+            for (int b = 0; b < 4; b++) t0[b] = ct[b];
+        } else {
+            const uint8_t* S0 = src + (long long)sy0 * P.stride;
+#pragma unroll
+            for (int b = 0; b < 4; b++) t0[b] = S0[sx[b]] * a0[b] + S0[sx1[b]] * a1[b];
+        }
+#pragma unroll
+        for (int b = 0; b < 4; b++) t1[b] = S1[sx[b]] * a0[b] + S1[sx1[b]] * a1[b];
+        uint32_t out = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const uint32_t v = (uint32_t)((((b0 * (t0[b] >> 4)) >> 16) + ((b1 * (t1[b] >> 4)) >> 16) + 2) >> 2) & 0xff;
+            out |= v << (8 * b);
+            ct[b] = t1[b];
+        }
+        cached_row = sy1;
+        *(uint32_t*)(dst + (long long)y * L.stride) = out & keep;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
-// FAST-9/16 corner measure M(p) = max(A, B): A = max over the 16 arcs of nine contiguous circle
-// pixels of min(v - I_k), B the same for (I_k - v).  p is a corner at threshold t iff M > t and
-// cv::FAST's score for it is M - 1 whatever t was (fast_score.cpp cornerScore<16>), so one
-// measure plane per level serves both the fastTh pass and the threshold-7 retry of
-// src/ORBextractor.cc:607-614.
-__device__ __forceinline__ int fast_measure(const uint8_t* __restrict__ p, int s) {
-    const int v = p[0];
-    int d[16];
-    d[0] = v - p[3 * s];
-    d[1] = v - p[3 * s + 1];
-    d[2] = v - p[2 * s + 2];
-    d[3] = v - p[s + 3];
-    d[4] = v - p[3];
-    d[5] = v - p[-s + 3];
-    d[6] = v - p[-2 * s + 2];
-    d[7] = v - p[-3 * s + 1];
-    d[8] = v - p[-3 * s];
-    d[9] = v - p[-3 * s - 1];
-    d[10] = v - p[-2 * s - 2];
-    d[11] = v - p[-s - 3];
-    d[12] = v - p[-3];
-    d[13] = v - p[s - 3];
-    d[14] = v - p[2 * s - 2];
-    d[15] = v - p[3 * s - 1];
-    int mn3[16], mx3[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        mn3[k] = min(d[k], min(d[(k + 1) & 15], d[(k + 2) & 15]));
-        mx3[k] = max(d[k], max(d[(k + 1) & 15], d[(k + 2) & 15]));
-    }
-    int A = -256, Bn = 256;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        A = max(A, min(mn3[k], min(mn3[(k + 3) & 15], mn3[(k + 6) & 15])));
-        Bn = min(Bn, max(mx3[k], max(mx3[(k + 3) & 15], mx3[(k + 6) & 15])));
-    }
-    return max(A, -Bn);
-}
-
 __global__ __launch_bounds__(256) void k_score(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score,
                                                const GeomDev* __restrict__ g, int level) {
     const LevelGeom& L = g->lv[level];
@@ -475,50 +464,77 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t* __restrict__ pyr,
 
 // ---------------------------------------------------------------------------------------------
 // GaussianBlur(level, level, Size(7,7), 2, 2, BORDER_REFLECT_101) on the level ROI
-// (src/ORBextractor.cc:760): separable integer taps, row pass in int32, column pass
-// (sum + 2^15) >> 16.  The filter border is the real 3-px ring of the padded plane.  Output goes
-// to a second plane whose 16-px margin is a copy of the unblurred margin: the in-place reference
-// leaves the margin unblurred and the descriptor pattern reaches up to 2 px into it.
-#define BLUR_TW 64
-#define BLUR_TH 16
+// (src/ORBextractor.cc:760): separable integer taps [18,34,49,55,49,34,18], row pass in int32,
+// column pass (sum + 2^15) >> 16.  The filter border is the real 3-px ring of the padded plane.
+// Output goes to a second plane whose 16-px margin is a copy of the unblurred margin: the in-place
+// reference leaves the margin unblurred and the descriptor pattern reaches up to 2 px into it.
+//
+// One thread owns a column of 4 pixels (one aligned dword) and walks BL_ROWS rows downwards.  Per
+// input row it loads three dwords (coalesced 256 B per wave), forms the four 7-tap row sums with
+// v_alignbyte + two v_dot4_u32_u8 each, and keeps the last seven rows of sums in registers (the
+// row loop is fully unrolled so the ring slots are static); per output row the column pass is
+// 7 integer ops per pixel.  No LDS: neighbouring lanes' overlapping loads hit the vector L1.
+#define BL_ROWS 32
 
 __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
                                               const GeomDev* __restrict__ g, int level, int t0, int t1, int t2, int t3) {
-    __shared__ uint8_t tile[BLUR_TH + 6][BLUR_TW + 8];
-    __shared__ int rows[BLUR_TH + 6][BLUR_TW];
     const LevelGeom& L = g->lv[level];
     const int f = blockIdx.z;
-    const int bx = blockIdx.x * BLUR_TW, by = blockIdx.y * BLUR_TH;  // padded coordinates
+    const int ndw = L.stride >> 2;
+    const int dwx = blockIdx.x * 64 + threadIdx.x;
+    const int y0 = (blockIdx.y * 4 + threadIdx.y) * BL_ROWS;
+    const int ph = L.ph;
+    if (dwx >= ndw || y0 >= ph) return;
     const long long base = (long long)f * g->frame_bytes + L.plane_off;
     const uint8_t* src = pyr + base;
-    const int pw = L.w + 2 * ORB_EDGE, ph = L.ph;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < (BLUR_TH + 6) * (BLUR_TW + 6); i += 256) {
-        const int ty = i / (BLUR_TW + 6), tx = i - ty * (BLUR_TW + 6);
-        const int yy = min(max(by + ty - 3, 0), ph - 1), xx = min(max(bx + tx - 3, 0), pw - 1);
-        tile[ty][tx] = src[(long long)yy * L.stride + xx];
-    }
-    __syncthreads();
-    for (int i = tid; i < (BLUR_TH + 6) * BLUR_TW; i += 256) {
-        const int ty = i / BLUR_TW, tx = i - ty * BLUR_TW;
-        const uint8_t* p = &tile[ty][tx];
-        rows[ty][tx] = t0 * (p[0] + p[6]) + t1 * (p[1] + p[5]) + t2 * (p[2] + p[4]) + t3 * p[3];
-    }
-    __syncthreads();
-    for (int i = tid; i < BLUR_TH * BLUR_TW; i += 256) {
-        const int ty = i / BLUR_TW, tx = i - ty * BLUR_TW;
-        const int x = bx + tx, y = by + ty;
-        if (x >= L.stride || y >= ph) continue;
-        uint8_t v;
-        if (x >= ORB_EDGE && x < L.w + ORB_EDGE && y >= ORB_EDGE && y < L.h + ORB_EDGE) {
-            const int acc = t0 * (rows[ty][tx] + rows[ty + 6][tx]) + t1 * (rows[ty + 1][tx] + rows[ty + 5][tx]) +
-                            t2 * (rows[ty + 2][tx] + rows[ty + 4][tx]) + t3 * rows[ty + 3][tx];
-            const int r = (acc + 32768) >> 16;
-            v = (uint8_t)min(max(r, 0), 255);
-        } else {
-            v = x < pw ? tile[ty + 3][tx + 3] : 0;
+    uint8_t* dst = blur + base;
+    const int stride = L.stride;
+    const int xl = max(dwx - 1, 0), xr = min(dwx + 1, ndw - 1);
+    const uint32_t tapsA = (uint32_t)t0 | ((uint32_t)t1 << 8) | ((uint32_t)t2 << 16) | ((uint32_t)t3 << 24);
+    const uint32_t tapsB = (uint32_t)t2 | ((uint32_t)t1 << 8) | ((uint32_t)t0 << 16);  // taps 4..6 = t2, t1, t0
+    // pixels of this dword inside the ROI columns [16, 16 + w)
+    const int px0 = dwx * 4;
+    uint32_t colmask = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (px0 + j >= ORB_EDGE && px0 + j < L.w + ORB_EDGE) colmask |= 0xffu << (8 * j);
+    uint32_t h[7][4];
+    uint32_t ctr[7];
+#pragma unroll
+    for (int i = 0; i < BL_ROWS + 6; i++) {
+        const int yy = min(max(y0 - 3 + i, 0), ph - 1);
+        const uint32_t* row = (const uint32_t*)(src + (long long)yy * stride);
+        const uint32_t a = row[xl], b = row[dwx], c = row[xr];
+        const int slot = i % 7;
+        ctr[slot] = b;
+        // bytes of (a, b, c) are columns px0-4 .. px0+7; pixel j needs byte offsets j+1 .. j+7
+        const uint32_t w1 = __builtin_amdgcn_alignbyte(b, a, 1), w2 = __builtin_amdgcn_alignbyte(b, a, 2);
+        const uint32_t w3 = __builtin_amdgcn_alignbyte(b, a, 3);
+        const uint32_t w5 = __builtin_amdgcn_alignbyte(c, b, 1), w6 = __builtin_amdgcn_alignbyte(c, b, 2);
+        const uint32_t w7 = __builtin_amdgcn_alignbyte(c, b, 3);
+        h[slot][0] = __builtin_amdgcn_udot4(w1, tapsA, __builtin_amdgcn_udot4(w5, tapsB, 0u, false), false);
+        h[slot][1] = __builtin_amdgcn_udot4(w2, tapsA, __builtin_amdgcn_udot4(w6, tapsB, 0u, false), false);
+        h[slot][2] = __builtin_amdgcn_udot4(w3, tapsA, __builtin_amdgcn_udot4(w7, tapsB, 0u, false), false);
+        h[slot][3] = __builtin_amdgcn_udot4(b, tapsA, __builtin_amdgcn_udot4(c, tapsB, 0u, false), false);
+        if (i >= 6) {
+            const int y = y0 + i - 6;
+            if (y < ph) {
+                uint32_t o = ctr[(i - 3) % 7];
+                if (y >= ORB_EDGE && y < L.h + ORB_EDGE && colmask) {
+                    uint32_t bl = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t acc = (uint32_t)t0 * (h[(i - 6) % 7][j] + h[i % 7][j]) +
+                                             (uint32_t)t1 * (h[(i - 5) % 7][j] + h[(i - 1) % 7][j]) +
+                                             (uint32_t)t2 * (h[(i - 4) % 7][j] + h[(i - 2) % 7][j]) +
+                                             (uint32_t)t3 * h[(i - 3) % 7][j];
+                        bl |= min((acc + 32768u) >> 16, 255u) << (8 * j);
+                    }
+                    o = (bl & colmask) | (o & ~colmask);
+                }
+                *(uint32_t*)(dst + (long long)y * stride + px0) = o;
+            }
         }
-        blur[base + (long long)y * L.stride + x] = v;
     }
 }
 
@@ -617,7 +633,7 @@ void launch_level0(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* 
 void launch_resize(hipStream_t st, const GeomDev& hg, int batch, int level, uint8_t* pyr, const GeomDev* dg,
                    const int* xofs, const uint32_t* xab, const uint32_t* ysrc, const uint32_t* yab) {
     const LevelGeom& L = hg.lv[level];
-    dim3 grid((L.stride / 4 + 63) / 64, (L.ph + 3) / 4, batch), block(64, 4);
+    dim3 grid((L.stride / 4 + 63) / 64, (L.ph + 4 * RZ_ROWS - 1) / (4 * RZ_ROWS), batch), block(64, 4);
     hipLaunchKernelGGL(k_resize, grid, block, 0, st, pyr, dg, level, xofs, xab, ysrc, yab);
 }
 
@@ -652,7 +668,7 @@ void launch_orient(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* 
 void launch_blur(hipStream_t st, const GeomDev& hg, int batch, int level, const uint8_t* pyr, uint8_t* blur,
                  const GeomDev* dg, const int taps[7]) {
     const LevelGeom& L = hg.lv[level];
-    dim3 grid((L.stride + BLUR_TW - 1) / BLUR_TW, (L.ph + BLUR_TH - 1) / BLUR_TH, batch), block(256);
+    dim3 grid((L.stride / 4 + 63) / 64, (L.ph + 4 * BL_ROWS - 1) / (4 * BL_ROWS), batch), block(64, 4);
     hipLaunchKernelGGL(k_blur, grid, block, 0, st, pyr, blur, dg, level, taps[0], taps[1], taps[2], taps[3]);
 }
 

@@ -75,7 +75,8 @@ struct orbhip_extractor {
     int cur_rows = 0, cur_cols = 0;
     GeomDev hg;
     std::vector<CellDesc> hcells;
-    int max_cell_h = 0;
+    int max_cell_h = 0, max_cell_w = 0;
+    bool fused_fast = false;  // every cell fits the LDS-resident fused FAST kernel
     int last_batch = 0;  // frames of the last chunk (for the stage taps)
 
     DeviceBuf d_geom, d_cells, d_xofs, d_xab, d_ysrc, d_yab, d_disc, d_pattern;
@@ -290,6 +291,10 @@ int set_size(orbhip_extractor* e, int rows, int cols, int batch) {
         e->hg = g;
         e->hcells.swap(cells);
         e->max_cell_h = mch;
+        e->max_cell_w = 0;
+        for (const CellDesc& c : e->hcells) e->max_cell_w = std::max(e->max_cell_w, c.cw);
+        const char* nf = getenv("ORBHIP_NO_FUSED_FAST");
+        e->fused_fast = orbk::fast_cell_supported(e->max_cell_w, e->max_cell_h) && !(nf && nf[0] == '1');
         e->cur_rows = rows;
         e->cur_cols = cols;
     }
@@ -298,7 +303,7 @@ int set_size(orbhip_extractor* e, int rows, int cols, int batch) {
     int rc;
     if ((rc = e->d_pyr.ensure(B * g.frame_bytes))) return rc;
     if ((rc = e->d_blur.ensure(B * g.frame_bytes))) return rc;
-    if ((rc = e->d_score.ensure(B * g.frame_bytes))) return rc;
+    if (!e->fused_fast && (rc = e->d_score.ensure(B * g.frame_bytes))) return rc;
     if ((rc = e->d_cand.ensure(std::max<size_t>(B * g.cand_per_frame * 4, 16)))) return rc;
     if ((rc = e->d_ntotal.ensure(B * g.cells_per_frame * 4))) return rc;
     if ((rc = e->d_nretain.ensure(B * g.cells_per_frame * 4))) return rc;
@@ -334,10 +339,15 @@ int run_chunk(orbhip_extractor* e, const uint8_t* d_imgs, int batch, long long r
         orbk::launch_resize(st, g, batch, l, pyr, dg, e->d_xofs.as<int>(), e->d_xab.as<uint32_t>(),
                             e->d_ysrc.as<uint32_t>(), e->d_yab.as<uint32_t>());
     STAGE_MARK(2);
-    for (int l = 0; l < g.nlevels; l++) orbk::launch_score(st, g, batch, l, pyr, e->d_score.as<uint8_t>(), dg);
+    if (!e->fused_fast)
+        for (int l = 0; l < g.nlevels; l++) orbk::launch_score(st, g, batch, l, pyr, e->d_score.as<uint8_t>(), dg);
     STAGE_MARK(3);
-    orbk::launch_nms(st, g, batch, e->max_cell_h, e->d_score.as<uint8_t>(), dg, e->d_cells.as<CellDesc>(),
-                     e->d_cand.as<uint32_t>(), e->d_ntotal.as<int>(), e->d_err.as<int>());
+    if (e->fused_fast)
+        orbk::launch_fast_cell(st, g, batch, e->max_cell_w, e->max_cell_h, pyr, dg, e->d_cells.as<CellDesc>(),
+                               e->d_cand.as<uint32_t>(), e->d_ntotal.as<int>(), e->d_err.as<int>());
+    else
+        orbk::launch_nms(st, g, batch, e->max_cell_h, e->d_score.as<uint8_t>(), dg, e->d_cells.as<CellDesc>(),
+                         e->d_cand.as<uint32_t>(), e->d_ntotal.as<int>(), e->d_err.as<int>());
     STAGE_MARK(4);
     orbk::launch_select(st, g, batch, dg, e->d_cells.as<CellDesc>(), e->d_cand.as<uint32_t>(), e->d_ntotal.as<int>(),
                         e->d_nretain.as<int>(), e->d_lvl.as<uint32_t>(), e->d_lvlcount.as<int>(), e->d_err.as<int>());
@@ -492,7 +502,7 @@ int orbhip_extractor_synchronize(orbhip_extractor* e) {
     if (hipEventElapsedTime(&e->last_ms, e->ev0, e->ev1) != hipSuccess) e->last_ms = 0.f;
     if (e->profiling) {
         const int nl = e->nlevels;
-        const int per_chunk[ORB_NSTAGES] = {1, nl - 1, nl, 1, 1, 1, nl, 1};
+        const int per_chunk[ORB_NSTAGES] = {1, nl - 1, e->fused_fast ? 0 : nl, 1, 1, 1, nl, 1};
         for (int s = 0; s < ORB_NSTAGES; s++) {
             e->stage_ms[s] = 0.f;
             e->stage_launches[s] = per_chunk[s] * e->prof_chunks;
@@ -584,6 +594,7 @@ int orbhip_debug_get(orbhip_extractor* e, int stage, int frame, int level, void*
     HIPCHK(hipStreamSynchronize(e->stream));
     const GeomDev& g = e->hg;
     const LevelGeom& L = g.lv[level];
+    if (stage == 2 && e->fused_fast) return orb_fail(ORBHIP_EUNSUPPORTED, "no measure plane: the fused FAST kernel keeps it in LDS");
     if (stage >= 0 && stage <= 2) {
         const int pw = L.w + 2 * ORB_EDGE;
         if (buf_bytes < (size_t)pw * L.ph) return orb_fail(ORBHIP_ECAP, "tap buffer too small");

@@ -65,7 +65,13 @@ def test_stages(orb, orbref, synth, case):
             b = sorted(map(tuple, dcand[o:o + n]))
             assert a == b, "level %d cell %d candidates" % (l, c)
             o += n
-        assert np.array_equal(ref.level_retain(l), dev.tap_cells(4, 0, l)), "level %d nToRetain" % l
+        retain = ref.level_retain(l)
+        assert np.array_equal(retain, dev.tap_cells(4, 0, l)), "level %d nToRetain" % l
+        o = 0
+        for c, n in enumerate(counts):  # a cell that keeps everything is never permuted: raster order
+            if n <= retain[c]:
+                assert np.array_equal(cand[o:o + n], dcand[o:o + n]), "level %d cell %d raster order" % (l, c)
+            o += n
         assert np.array_equal(ref.level_keypoints(l), dev.tap_level_keypoints(0, l)), "level %d selection" % l
     for l in range(nl):
         rb = ref.plane(l, blurred=True)
