@@ -155,7 +155,9 @@ float orbhip_matcher_last_elapsed_ms(orbhip_matcher* m);
  *       1: n float angles (radians) -> n (cos, sin) float pairs as the descriptor kernel computes them
  *       2: n uint32 keys (score in bits 31..24), aux = nth -> the keys as the device's
  *          nth_element leaves them
- *       3: n 7x7 u8 patches -> n int32 FAST corner measures of the patch centres */
+ *       3: n 7x7 u8 patches -> n int32 FAST corner measures of the patch centres
+ *       4: as 2 with the wave-cooperative selection the extractor runs (n <= 4096)
+ *       5: as 4 with the introselect depth limit forced to 1 (reaches the heap-select branch) */
 int orbhip_selftest(int which, const void* in, int n, int aux, void* out);
 
 /* Library/device facts. */

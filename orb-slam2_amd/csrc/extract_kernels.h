@@ -35,6 +35,7 @@ void launch_describe(hipStream_t st, const GeomDev& hg, int batch, const uint8_t
 void launch_test_atan2(hipStream_t st, const float* yx, float* out, int n);
 void launch_test_sincos(hipStream_t st, const float* in, float* out, int n);
 void launch_test_select(hipStream_t st, uint32_t* keys, int n, int nth);
+void launch_test_wave_select(hipStream_t st, uint32_t* keys, int n, int nth, int depth);
 void launch_test_measure(hipStream_t st, const uint8_t* patches, int* out, int n);
 }  // namespace orbk
 #endif

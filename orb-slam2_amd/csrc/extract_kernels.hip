@@ -11,6 +11,7 @@
 #include "extract_kernels.h"
 #include "fast_measure.h"
 #include "introselect.h"
+#include "wave_select.h"
 #include "sincos_port.h"
 
 namespace orbk {
@@ -269,17 +270,36 @@ __global__ __launch_bounds__(256) void k_nms(const uint8_t* __restrict__ score, 
 // ---------------------------------------------------------------------------------------------
 // Quota redistribution (src/ORBextractor.cc:622-670), per-cell retainBest (:683-685), cell-major
 // concatenation in level coordinates (:687-694) and per-level retainBest (:697-701).
-// One workgroup per (level, frame).  The selections are serial algorithms (see introselect.h)
-// run by one lane on a list staged in LDS.
-#define SEL_BUF_KEYS 12032
-#define SEL_WAVE_KEYS (SEL_BUF_KEYS / 4)
+// One workgroup per (level, frame).
+//   phase 1  quota loop: every pass over the cells is order-independent (sums and per-cell
+//            decisions), so it runs data-parallel with block reductions; the while loop itself is
+//            the reference's.
+//   phase 2  per-cell selection: one wave per cell, list staged in LDS, exact std::nth_element
+//            element movement with wave-parallel partitions (wave_select.h).
+//   phase 3  exclusive scan of nToRetain -> offsets; gather of the retained prefixes.
+//   phase 4  per-level selection by one wave.
+// Lists larger than the LDS staging areas are selected in place in global memory by one lane
+// (introselect.h) — same results, only slower.
+#define SEL_WCAP 1536
+#define SEL_LCAP (4 * SEL_WCAP)
+
+__device__ __forceinline__ int block_sum(int v, int* red, int tid) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
 
 __global__ __launch_bounds__(256) void k_select(const GeomDev* __restrict__ g, const CellDesc* __restrict__ cells,
                                                 uint32_t* __restrict__ cand, const int* __restrict__ n_total,
                                                 int* __restrict__ n_retain, uint32_t* __restrict__ lvl_list,
                                                 int* __restrict__ lvl_count, int* __restrict__ err) {
-    __shared__ uint32_t buf[SEL_BUF_KEYS];
+    __shared__ uint32_t buf[SEL_LCAP];
+    __shared__ uint16_t lists[2 * SEL_LCAP];
     __shared__ int aux[ORB_MAX_CELLS_PER_LEVEL + 1];
+    __shared__ int red[4];
     const int level = blockIdx.x, f = blockIdx.y;
     const LevelGeom& L = g->lv[level];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -289,93 +309,119 @@ __global__ __launch_bounds__(256) void k_select(const GeomDev* __restrict__ g, c
     int* ret = n_retain + (long long)f * g->cells_per_frame + L.cell_base;
     uint32_t* fcand = cand + (long long)f * g->cand_per_frame;
 
-    if (tid == 0) {
-        const int nfc = L.nfeaturesCell;
-        int nNoMore = 0, nToDistribute = 0;
-        for (int c = 0; c < nCells; c++) {
+    // ---- phase 1 ------------------------------------------------------------------------------
+    int* ltot = (int*)lists;               // nCells ints
+    int* lret = ltot + ORB_MAX_CELLS_PER_LEVEL;  // nCells ints (lists holds 2*SEL_LCAP*2 bytes >= 2*2048*4)
+    const int nfc = L.nfeaturesCell;
+    {
+        int d = 0, closed = 0;
+        for (int c = tid; c < nCells; c += 256) {
             const bool skipped = lc[c].cw <= 0 || lc[c].ch <= 0;
             const int nKeys = tot[c];
+            ltot[c] = nKeys;
             if (skipped) {
-                ret[c] = 0;
+                lret[c] = 0;
                 aux[c] = 0;
             } else if (nKeys > nfc) {
-                ret[c] = nfc;
+                lret[c] = nfc;
                 aux[c] = 0;
             } else {
-                ret[c] = nKeys;
-                nToDistribute += nfc - nKeys;
+                lret[c] = nKeys;
+                d += nfc - nKeys;
                 aux[c] = 1;
-                nNoMore++;
+                closed++;
             }
         }
+        int nToDistribute = block_sum(d, red, tid);
+        int nNoMore = block_sum(closed, red, tid);
         while (nToDistribute > 0 && nNoMore < nCells) {
             const int nNew = nfc + (int)ceilf((float)nToDistribute / (float)(nCells - nNoMore));
-            nToDistribute = 0;
-            for (int c = 0; c < nCells; c++)
+            d = 0;
+            closed = 0;
+            for (int c = tid; c < nCells; c += 256)
                 if (!aux[c]) {
-                    const int nt = tot[c];
+                    const int nt = ltot[c];
                     if (nt > nNew) {
-                        ret[c] = nNew;
+                        lret[c] = nNew;
                     } else {
-                        ret[c] = nt;
-                        nToDistribute += nNew - nt;
+                        lret[c] = nt;
+                        d += nNew - nt;
                         aux[c] = 1;
-                        nNoMore++;
+                        closed++;
                     }
                 }
+            nToDistribute = block_sum(d, red, tid);
+            nNoMore += block_sum(closed, red, tid);
+        }
+        __syncthreads();
+        for (int c = tid; c < nCells; c += 256) {
+            const int r = lret[c];
+            aux[c] = r;
+            ret[c] = r;
+        }
+        __syncthreads();
+    }
+
+    // ---- phase 2: waves are independent, no block barrier inside --------------------------------
+    {
+        uint32_t* wbuf = buf + wave * SEL_WCAP;
+        uint16_t* wl = lists + wave * 2 * SEL_WCAP;
+        uint16_t* wr = wl + SEL_WCAP;
+        for (int c = wave; c < nCells; c += 4) {
+            const int n = tot[c], kk = aux[c];
+            if (!(n > kk && kk > 0)) continue;
+            uint32_t* list = fcand + lc[c].cand_off;
+            if (n <= SEL_WCAP) {
+                for (int i = lane; i < n; i += 64) wbuf[i] = list[i];
+                orbsel::wave_lds_fence();
+                orbsel::wave_nth_element_desc(wbuf, n, kk, wl, wr, lane);
+                // the whole permuted list goes back, so the cell list stays a permutation
+                for (int i = lane; i < n; i += 64) list[i] = wbuf[i];
+                orbsel::wave_lds_fence();
+            } else if (lane == 0) {
+                orbsel::nth_element_desc(list, n, kk);
+            }
         }
     }
     __threadfence_block();
     __syncthreads();
 
-    // per-cell selection: wave w takes cells w, w+4, ...; uniform trip count so barriers match
-    uint32_t* wbuf = buf + wave * SEL_WAVE_KEYS;
-    for (int c0 = 0; c0 < nCells; c0 += 4) {
-        const int c = c0 + wave;
-        int n = 0, kk = 0;
-        uint32_t* list = nullptr;
-        if (c < nCells) {
-            n = tot[c];
-            kk = ret[c];
-            list = fcand + lc[c].cand_off;
+    // ---- phase 3: exclusive scan of nToRetain over the cells (8 consecutive cells per thread) ----
+    {
+        const int per = (nCells + 255) / 256;
+        const int c0 = min(tid * per, nCells), c1 = min(c0 + per, nCells);
+        int s = 0;
+        for (int c = c0; c < c1; c++) s += aux[c];
+        int incl = s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
         }
-        const bool need = c < nCells && n > kk && kk > 0;
-        const bool staged = need && n <= SEL_WAVE_KEYS;
-        if (staged)
-            for (int i = lane; i < n; i += 64) wbuf[i] = list[i];
+        if (lane == 63) red[wave] = incl;
         __syncthreads();
-        if (need && lane == 0) {
-            if (staged) orbsel::nth_element_desc(wbuf, n, kk);
-            else orbsel::nth_element_desc(list, n, kk);
+        int woff = 0;
+        for (int w2 = 0; w2 < wave; w2++) woff += red[w2];
+        const int grand = red[0] + red[1] + red[2] + red[3];
+        int run = woff + incl - s;
+        for (int c = c0; c < c1; c++) {
+            const int r = aux[c];
+            aux[c] = run;
+            run += r;
         }
+        if (tid == 0) aux[nCells] = grand;
         __syncthreads();
-        if (staged)  // the whole permuted list goes back, so the cell list stays a permutation
-            for (int i = lane; i < n; i += 64) list[i] = wbuf[i];
     }
-    __threadfence_block();
-    __syncthreads();
-
-    // offsets of the cells' retained prefixes in the level list
-    if (tid == 0) {
-        int a = 0;
-        for (int c = 0; c < nCells; c++) {
-            const int r = ret[c];
-            aux[c] = a;
-            a += r;
-        }
-        aux[nCells] = a;
-    }
-    __syncthreads();
     int total = aux[nCells];
     uint32_t* ll = lvl_list + (long long)f * g->lvl_per_frame + L.lvl_off;
     if (total > L.lvl_cap) {
         if (tid == 0) atomicOr(err, 2);
         total = L.lvl_cap;
     }
-    const bool lstaged = total <= SEL_BUF_KEYS;
+    const bool lstaged = total <= SEL_LCAP;
     uint32_t* dst = lstaged ? buf : ll;
     for (int c = wave; c < nCells; c += 4) {
-        const int r = ret[c], o = aux[c];
+        const int o = aux[c], r = aux[c + 1] - o;
         const uint32_t* list = fcand + lc[c].cand_off;
         const uint32_t add = ((uint32_t)lc[c].ini_y << 12) + (uint32_t)lc[c].ini_x;
         for (int i = lane; i < r; i += 64)
@@ -383,8 +429,16 @@ __global__ __launch_bounds__(256) void k_select(const GeomDev* __restrict__ g, c
     }
     __threadfence_block();
     __syncthreads();
+
+    // ---- phase 4 ------------------------------------------------------------------------------
     const int quota = L.quota;
-    if (total > quota && tid == 0) orbsel::nth_element_desc(dst, total, quota);
+    if (total > quota) {
+        if (lstaged) {
+            if (wave == 0) orbsel::wave_nth_element_desc(buf, total, quota, lists, lists + SEL_LCAP, lane);
+        } else if (tid == 0) {
+            orbsel::nth_element_desc(ll, total, quota);
+        }
+    }
     __syncthreads();
     const int count = min(total, quota);
     if (lstaged)
@@ -612,6 +666,15 @@ __global__ void k_test_sincos(const float* in, float* out, int n) {
 __global__ void k_test_select(uint32_t* keys, int n, int nth) {
     if (blockIdx.x == 0 && threadIdx.x == 0) orbsel::nth_element_desc(keys, n, nth);
 }
+__global__ void k_test_wave_select(uint32_t* keys, int n, int nth, int depth) {
+    __shared__ uint32_t v[4096];
+    __shared__ uint16_t lp[4096], rp[4096];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < n; i += 64) v[i] = keys[i];
+    orbsel::wave_lds_fence();
+    orbsel::wave_nth_element_desc(v, n, nth, lp, rp, lane, depth);
+    for (int i = lane; i < n; i += 64) keys[i] = v[i];
+}
 __global__ void k_test_measure(const uint8_t* patches, int* out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = fast_measure(patches + (long long)i * 49 + 24, 7);
@@ -688,6 +751,9 @@ void launch_test_sincos(hipStream_t st, const float* in, float* out, int n) {
 }
 void launch_test_select(hipStream_t st, uint32_t* keys, int n, int nth) {
     hipLaunchKernelGGL(k_test_select, dim3(1), dim3(64), 0, st, keys, n, nth);
+}
+void launch_test_wave_select(hipStream_t st, uint32_t* keys, int n, int nth, int depth) {
+    hipLaunchKernelGGL(k_test_wave_select, dim3(1), dim3(64), 0, st, keys, n, nth, depth);
 }
 void launch_test_measure(hipStream_t st, const uint8_t* patches, int* out, int n) {
     hipLaunchKernelGGL(k_test_measure, dim3((n + 255) / 256), dim3(256), 0, st, patches, out, n);

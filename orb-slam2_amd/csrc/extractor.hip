@@ -655,12 +655,15 @@ int orbhip_debug_get(orbhip_extractor* e, int stage, int frame, int level, void*
 // Device self-tests of arithmetic helpers (test instrumentation; declared in orbhip_test.h).
 int orbhip_selftest(int which, const void* in, int n, int aux, void* out) {
     if (n <= 0) return ORBHIP_OK;
+    if ((which == 4 || which == 5) && n > 4096) return orb_fail(ORBHIP_EINVAL, "wave select selftest holds at most 4096 keys");
     size_t in_bytes, out_bytes;
     switch (which) {
         case 0: in_bytes = 8ull * n; out_bytes = 4ull * n; break;   // atan2: (y, x) pairs -> degrees
         case 1: in_bytes = 4ull * n; out_bytes = 8ull * n; break;   // angle -> (cos, sin)
         case 2: in_bytes = 4ull * n; out_bytes = 4ull * n; break;   // keys, nth = aux -> permuted keys
         case 3: in_bytes = 49ull * n; out_bytes = 4ull * n; break;  // 7x7 patches -> corner measure
+        case 4: in_bytes = 4ull * n; out_bytes = 4ull * n; break;   // keys, wave-cooperative nth_element (n <= 4096)
+        case 5: in_bytes = 4ull * n; out_bytes = 4ull * n; break;   // the same with depth limit 0 (heap-select branch)
         default: return orb_fail(ORBHIP_EINVAL, "unknown selftest");
     }
     void *din = nullptr, *dout = nullptr;
@@ -677,9 +680,11 @@ int orbhip_selftest(int which, const void* in, int n, int aux, void* out) {
             orbk::launch_test_select(0, (uint32_t*)din, n, aux);
             break;
         case 3: orbk::launch_test_measure(0, (const uint8_t*)din, (int*)dout, n); break;
+        case 4: orbk::launch_test_wave_select(0, (uint32_t*)din, n, aux, -1); break;
+        case 5: orbk::launch_test_wave_select(0, (uint32_t*)din, n, aux, 1); break;
     }
     hipError_t err = hipDeviceSynchronize();
-    if (err == hipSuccess) err = hipMemcpy(out, which == 2 ? din : dout, out_bytes, hipMemcpyDeviceToHost);
+    if (err == hipSuccess) err = hipMemcpy(out, (which == 2 || which == 4 || which == 5) ? din : dout, out_bytes, hipMemcpyDeviceToHost);
     hipFree(din);
     hipFree(dout);
     if (err != hipSuccess) return orb_fail(ORBHIP_EHIP, "selftest failed: %s", hipGetErrorString(err));

@@ -11,7 +11,7 @@
 #define ORB_HALF_PATCH 15    // HALF_PATCH_SIZE, :76
 #define ORB_DISC_PIXELS 749  // pixels of the radius-15 disc the orientation moment runs over
 #define ORB_MAX_DIM 4095     // keypoint keys hold 12-bit coordinates
-#define ORB_MAX_CELLS_PER_LEVEL 4096
+#define ORB_MAX_CELLS_PER_LEVEL 2048
 
 struct LevelGeom {
     int w, h;              // level image (ROI) size

@@ -68,6 +68,40 @@ def test_device_nth_element_matches_libstdcxx(orb, orbref, n, mode):
         assert np.array_equal(out[:k] & 0xFFFFFF, perm[:k].astype(np.uint32)), (n, k)
 
 
+@pytest.mark.parametrize("which", [4, 5])
+@pytest.mark.parametrize("n,mode", [(4, 0), (5, 1), (17, 0), (64, 1), (65, 0), (100, 0), (129, 2), (480, 0), (600, 1),
+                                    (1536, 0), (3000, 0), (4096, 2)])
+def test_wave_cooperative_nth_element_matches_libstdcxx(orb, orbref, n, mode, which):
+    """The wave-parallel partition must move elements exactly like the serial scan: whole-array
+    permutation equality with std::nth_element (which 4) and with libstdc++'s __introselect at
+    depth limit 1, which takes the heap-select branch (which 5; compared on the kept prefix set)."""
+    rng = np.random.default_rng(1000 * which + n + mode)
+    if mode == 0:
+        score = rng.integers(7, 12, n)
+    elif mode == 1:
+        score = rng.integers(0, 255, n)
+    else:
+        score = np.where(rng.integers(0, 8, n) == 0, rng.integers(0, 255, n), 20)
+    keys = (score.astype(np.uint32) << 24) | np.arange(n, dtype=np.uint32)
+    for k in sorted({1, n // 7 + 1, n // 2, n - 1}):
+        if not 0 < k < n:
+            continue
+        wave = np.zeros(n, np.uint32)
+        orb._lib.check(orb._lib.lib().orbhip_selftest(which, _p(keys), n, k, _p(wave)))
+        if which == 4:
+            serial = np.zeros(n, np.uint32)
+            orb._lib.check(orb._lib.lib().orbhip_selftest(2, _p(keys), n, k, _p(serial)))
+            assert np.array_equal(wave, serial), (n, k)  # serial device version is itself pinned to libstdc++
+            perm = np.zeros(n, np.int32)
+            resp = score.astype(np.float32)
+            assert orbref.lib().orbref_nth_prefix(_p(resp), n, k, _p(perm)) == k
+            assert np.array_equal(wave[:k] & 0xFFFFFF, perm[:k].astype(np.uint32)), (n, k)
+        else:
+            assert sorted(wave & 0xFFFFFF) == list(range(n))
+            kept = np.sort(score[(wave[:k] & 0xFFFFFF).astype(int)])[::-1]
+            assert np.array_equal(kept, np.sort(score)[::-1][:k])
+
+
 def test_corner_measure_matches_opencv_style_score(orb, orbref):
     rng = np.random.default_rng(3)
     n = 50000
