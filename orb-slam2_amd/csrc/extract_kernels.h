@@ -26,7 +26,7 @@ void launch_fast_cell(hipStream_t st, const GeomDev& hg, int batch, int max_cw, 
 void launch_select(hipStream_t st, const GeomDev& hg, int batch, const GeomDev* dg, const CellDesc* cells,
                    uint32_t* cand, const int* n_total, int* n_retain, uint32_t* lvl_list, int* lvl_count, int* err);
 void launch_orient(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* pyr, const GeomDev* dg,
-                   const uint32_t* lvl_list, const int* lvl_count, const int* disc, float* angles);
+                   const uint32_t* lvl_list, const int* lvl_count, const uint32_t* otab, float* angles);
 void launch_blur(hipStream_t st, const GeomDev& hg, int batch, int level, const uint8_t* pyr, uint8_t* blur,
                  const GeomDev* dg, const int taps[7]);
 void launch_describe(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* blur, const GeomDev* dg,

@@ -487,10 +487,16 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 }
 
 // IC_Angle (src/ORBextractor.cc:124-151): intensity-centroid moments over the radius-15 disc of
-// the UNBLURRED level image, one wave per keypoint, lanes striding over the 749 disc pixels.
+// the UNBLURRED level image, one wave per keypoint.  The 31 disc rows are covered by 31 x 8
+// (unaligned) dword loads, four pixels each; a host-built table gives, per dword, the byte weights
+// (u + 16 inside the disc, else 0) and the inside mask, so that with two v_dot4_u32_u8
+//   sum(u * I) = dot4(I, u + 16) - 16 * dot4(I, mask),   sum(v * I) = v * dot4(I, mask).
+// The moments are exact integers whatever the summation order.
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+
 __global__ __launch_bounds__(256) void k_orient(const uint8_t* __restrict__ pyr, const GeomDev* __restrict__ g,
                                                 const uint32_t* __restrict__ lvl_list, const int* __restrict__ lvl_count,
-                                                const int* __restrict__ disc, float* __restrict__ angles) {
+                                                const uint32_t* __restrict__ otab, float* __restrict__ angles) {
     const int f = blockIdx.y;
     const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -499,14 +505,21 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t* __restrict__ pyr,
     if (!slot_to_key(g, lvl_list, lvl_count, f, slot, level, k, key, oi)) return;
     const LevelGeom& L = g->lv[level];
     const int x = key & 0xfff, y = (key >> 12) & 0xfff;
-    const uint8_t* center = pyr + (long long)f * g->frame_bytes + L.plane_off + (long long)(y + ORB_EDGE) * L.stride + (x + ORB_EDGE);
+    const int stride = L.stride;
+    const uint8_t* center = pyr + (long long)f * g->frame_bytes + L.plane_off + (long long)(y + ORB_EDGE) * stride + (x + ORB_EDGE);
     int m10 = 0, m01 = 0;
-    for (int i = lane; i < ORB_DISC_PIXELS; i += 64) {
-        const int uv = disc[i];
-        const int u = (int)(int8_t)(uv & 0xff), v = (int)(int8_t)((uv >> 8) & 0xff);
-        const int val = center[v * L.stride + u];
-        m10 += u * val;
-        m01 += v * val;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const int idx = it * 64 + lane;
+        if (idx < 31 * 8) {
+            const int v = (idx >> 3) - ORB_HALF_PATCH;
+            const uint32_t I = *(const u32_unaligned*)(center + v * stride - ORB_HALF_PATCH + 4 * (idx & 7));
+            const uint2 w = ((const uint2*)otab)[idx];
+            const int s = (int)__builtin_amdgcn_udot4(I, w.y, 0u, false);
+            const int t = (int)__builtin_amdgcn_udot4(I, w.x, 0u, false);
+            m10 += t - 16 * s;
+            m01 += v * s;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -723,9 +736,9 @@ void launch_select(hipStream_t st, const GeomDev& hg, int batch, const GeomDev* 
 }
 
 void launch_orient(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* pyr, const GeomDev* dg,
-                   const uint32_t* lvl_list, const int* lvl_count, const int* disc, float* angles) {
+                   const uint32_t* lvl_list, const int* lvl_count, const uint32_t* otab, float* angles) {
     dim3 grid((hg.nfeatures + 3) / 4, batch), block(256);
-    hipLaunchKernelGGL(k_orient, grid, block, 0, st, pyr, dg, lvl_list, lvl_count, disc, angles);
+    hipLaunchKernelGGL(k_orient, grid, block, 0, st, pyr, dg, lvl_list, lvl_count, otab, angles);
 }
 
 void launch_blur(hipStream_t st, const GeomDev& hg, int batch, int level, const uint8_t* pyr, uint8_t* blur,

@@ -352,7 +352,7 @@ int run_chunk(orbhip_extractor* e, const uint8_t* d_imgs, int batch, long long r
     orbk::launch_select(st, g, batch, dg, e->d_cells.as<CellDesc>(), e->d_cand.as<uint32_t>(), e->d_ntotal.as<int>(),
                         e->d_nretain.as<int>(), e->d_lvl.as<uint32_t>(), e->d_lvlcount.as<int>(), e->d_err.as<int>());
     STAGE_MARK(5);
-    orbk::launch_orient(st, g, batch, pyr, dg, e->d_lvl.as<uint32_t>(), e->d_lvlcount.as<int>(), e->d_disc.as<int>(),
+    orbk::launch_orient(st, g, batch, pyr, dg, e->d_lvl.as<uint32_t>(), e->d_lvlcount.as<int>(), e->d_disc.as<uint32_t>(),
                         e->d_angles.as<float>());
     STAGE_MARK(6);
     for (int l = 0; l < g.nlevels; l++) orbk::launch_blur(st, g, batch, l, pyr, e->d_blur.as<uint8_t>(), dg, e->gtaps);
@@ -415,17 +415,30 @@ int orbhip_extractor_create(orbhip_extractor** out, int nfeatures, float scale_f
             rc = orb_fail(ORBHIP_EHIP, "stream/event creation failed");
             break;
         }
-        // disc pixel table in the order IC_Angle visits them (order is irrelevant to the integer sums)
-        std::vector<int> disc;
-        for (int v = -ORB_HALF_PATCH; v <= ORB_HALF_PATCH; v++) {
-            const int d = e->umax[v < 0 ? -v : v];
-            for (int u = -d; u <= d; u++) disc.push_back((u & 0xff) | ((v & 0xff) << 8));
-        }
-        if ((int)disc.size() != ORB_DISC_PIXELS) {
-            rc = orb_fail(ORBHIP_EINVAL, "disc has %zu pixels", disc.size());
+        // orientation table: per (disc row v, dword j) the byte weights u + 16 (0 outside the disc) and
+        // the inside mask of the four pixels u = -15 + 4j .. -12 + 4j
+        std::vector<uint32_t> otab(2 * 256, 0u);
+        int inside_total = 0;
+        for (int r = 0; r < 31; r++)
+            for (int j = 0; j < 8; j++) {
+                const int v = r - ORB_HALF_PATCH, d = e->umax[v < 0 ? -v : v];
+                uint32_t wu = 0, mk = 0;
+                for (int b = 0; b < 4; b++) {
+                    const int u = -ORB_HALF_PATCH + 4 * j + b;
+                    if (u >= -d && u <= d) {
+                        wu |= (uint32_t)(u + 16) << (8 * b);
+                        mk |= 1u << (8 * b);
+                        inside_total++;
+                    }
+                }
+                otab[2 * (r * 8 + j)] = wu;
+                otab[2 * (r * 8 + j) + 1] = mk;
+            }
+        if (inside_total != ORB_DISC_PIXELS) {
+            rc = orb_fail(ORBHIP_EINVAL, "disc has %d pixels", inside_total);
             break;
         }
-        if ((rc = upload(e->d_disc, disc.data(), disc.size() * sizeof(int), e->stream))) break;
+        if ((rc = upload(e->d_disc, otab.data(), otab.size() * sizeof(uint32_t), e->stream))) break;
         if ((rc = upload(e->d_pattern, kPattern, sizeof(kPattern), e->stream))) break;
         if ((rc = e->d_err.ensure(16))) break;
         if (hipMemset(e->d_err.p, 0, 16) != hipSuccess) {
