@@ -52,57 +52,41 @@ __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ imgs
 // Level l >= 1: resize(level l-1 ROI -> level l ROI, INTER_LINEAR) then copyMakeBorder
 // REFLECT_101 (src/ORBextractor.cc:800-807), fused: every padded pixel is computed from the
 // interior pixel it reflects to.  Coefficient tables hold OpenCV's 11-bit fixed-point weights.
-// One thread owns an aligned dword column (4 pixels) and walks RZ_ROWS rows: its four column
-// entries (source offset, weights) are loaded once, the row entries are wave-uniform, and the
-// horizontal interpolation of the lower source row is kept for the next output row, which usually
-// needs it as its upper row (the scale is < 2).
+// One workgroup produces a 256 x 32 pixel tile of the padded destination plane: it finds the
+// source rectangle its pixels read (column and row maps are monotone up to the border
+// reflection, so min/max of the per-thread entries bound it), stages that rectangle into LDS with
+// aligned 16-byte loads, and interpolates out of LDS.  One thread owns an aligned dword column
+// (4 pixels) of RZ_ROWS rows and keeps the horizontal interpolation of the lower source row for
+// the next output row, which usually needs it as its upper row.
 #define RZ_ROWS 8
+#define RZ_TILE_H (4 * RZ_ROWS)
 
-__global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, const GeomDev* __restrict__ g, int level,
-                                                const int* __restrict__ xofs, const uint32_t* __restrict__ xab,
-                                                const uint32_t* __restrict__ ysrc, const uint32_t* __restrict__ yab) {
-    const LevelGeom& L = g->lv[level];
-    const LevelGeom& P = g->lv[level - 1];
-    const int dwx = blockIdx.x * 64 + threadIdx.x;
-    const int ybase = (blockIdx.y * 4 + threadIdx.y) * RZ_ROWS;
-    const int f = blockIdx.z;
-    if (dwx * 4 >= L.stride || ybase >= L.ph) return;
-    uint8_t* frame = pyr + (long long)f * g->frame_bytes;
-    const uint8_t* src = frame + P.plane_off + (long long)ORB_EDGE * P.stride + ORB_EDGE;
-    uint8_t* dst = frame + L.plane_off + dwx * 4;
-    int sx[4], sx1[4], a0[4], a1[4];
-    uint32_t keep = 0;  // bytes of the dword that are inside the padded plane
-#pragma unroll
-    for (int b = 0; b < 4; b++) {
-        const int x = dwx * 4 + b;
-        if (x < L.w + 2 * ORB_EDGE) keep |= 0xffu << (8 * b);
-        const int dx = reflect101(min(x, L.w + 2 * ORB_EDGE - 1) - ORB_EDGE, L.w);
-        sx[b] = xofs[L.rz_x_off + dx];
-        sx1[b] = min(sx[b] + 1, P.w - 1);
-        const uint32_t xa = xab[L.rz_x_off + dx];
-        a0[b] = xa & 0xffff;
-        a1[b] = xa >> 16;
-    }
+// Rows [ybase, yend) of one dword column: vertical pass of cv::resize over horizontally
+// interpolated source rows read from `rows` (row r at rows + (r - row0) * rpitch).
+__device__ __forceinline__ void resize_rows(const uint8_t* __restrict__ rows, int rpitch, int row0, const int sx[4],
+                                            const int sx1[4], const int a0[4], const int a1[4],
+                                            const uint32_t* __restrict__ ytab_s, const uint32_t* __restrict__ ytab_b,
+                                            int ybase, int yend, int h, uint8_t* __restrict__ dst, int dstride,
+                                            uint32_t keep) {
     int cached_row = -1;
     int ct[4] = {0, 0, 0, 0};
-    const int yend = min(ybase + RZ_ROWS, L.ph);
     for (int y = ybase; y < yend; y++) {
-        const int dy = reflect101(y - ORB_EDGE, L.h);
-        const uint32_t ys = ysrc[L.rz_y_off + dy], yb = yab[L.rz_y_off + dy];
+        const int dy = reflect101(y - ORB_EDGE, h);
+        const uint32_t ys = ytab_s[dy], yb = ytab_b[dy];
         const int sy0 = ys & 0xffff, sy1 = ys >> 16;
         const int b0 = yb & 0xffff, b1 = yb >> 16;
-        const uint8_t* S1 = src + (long long)sy1 * P.stride;
+        const int o1 = (sy1 - row0) * rpitch;
         int t0[4], t1[4];
         if (sy0 == cached_row) {
 #pragma unroll
             for (int b = 0; b < 4; b++) t0[b] = ct[b];
         } else {
-            const uint8_t* S0 = src + (long long)sy0 * P.stride;
+            const int o0 = (sy0 - row0) * rpitch;
 #pragma unroll
-            for (int b = 0; b < 4; b++) t0[b] = S0[sx[b]] * a0[b] + S0[sx1[b]] * a1[b];
+            for (int b = 0; b < 4; b++) t0[b] = rows[o0 + sx[b]] * a0[b] + rows[o0 + sx1[b]] * a1[b];
         }
 #pragma unroll
-        for (int b = 0; b < 4; b++) t1[b] = S1[sx[b]] * a0[b] + S1[sx1[b]] * a1[b];
+        for (int b = 0; b < 4; b++) t1[b] = rows[o1 + sx[b]] * a0[b] + rows[o1 + sx1[b]] * a1[b];
         uint32_t out = 0;
 #pragma unroll
         for (int b = 0; b < 4; b++) {
@@ -111,7 +95,102 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, const
             ct[b] = t1[b];
         }
         cached_row = sy1;
-        *(uint32_t*)(dst + (long long)y * L.stride) = out & keep;
+        *(uint32_t*)(dst + (long long)y * dstride) = out & keep;
+    }
+}
+
+
+__global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, const GeomDev* __restrict__ g, int level,
+                                                const int* __restrict__ xofs, const uint32_t* __restrict__ xab,
+                                                const uint32_t* __restrict__ ysrc, const uint32_t* __restrict__ yab,
+                                                int lds_pitch, int lds_rows) {
+    extern __shared__ uint4 rz_lds[];
+    __shared__ int bounds[4];  // min sx, max sx1, min sy0, max sy1
+    const LevelGeom& L = g->lv[level];
+    const LevelGeom& P = g->lv[level - 1];
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const int dwx = blockIdx.x * 64 + threadIdx.x;
+    const int ybase = (blockIdx.y * 4 + threadIdx.y) * RZ_ROWS;
+    const int f = blockIdx.z;
+    uint8_t* frame = pyr + (long long)f * g->frame_bytes;
+    const uint8_t* src = frame + P.plane_off + (long long)ORB_EDGE * P.stride + ORB_EDGE;
+    const bool col_ok = dwx * 4 < L.stride;
+    const int pw = L.w + 2 * ORB_EDGE;
+    if (tid == 0) {
+        bounds[0] = 0x7fffffff;
+        bounds[1] = 0;
+        bounds[2] = 0x7fffffff;
+        bounds[3] = 0;
+    }
+    int sx[4], sx1[4], a0[4], a1[4];
+    uint32_t keep = 0;  // bytes of the dword that are inside the padded plane
+    int mn = 0x7fffffff, mx = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const int x = min(dwx * 4 + b, pw - 1);
+        if (dwx * 4 + b < pw) keep |= 0xffu << (8 * b);
+        const int dx = reflect101(x - ORB_EDGE, L.w);
+        sx[b] = xofs[L.rz_x_off + dx];
+        sx1[b] = min(sx[b] + 1, P.w - 1);
+        const uint32_t xa = xab[L.rz_x_off + dx];
+        a0[b] = xa & 0xffff;
+        a1[b] = xa >> 16;
+        mn = min(mn, sx[b]);
+        mx = max(mx, sx1[b]);
+    }
+    const int yend = min(ybase + RZ_ROWS, L.ph);
+    int ymn = 0x7fffffff, ymx = 0;
+    for (int y = ybase; y < yend; y++) {
+        const uint32_t ys = ysrc[L.rz_y_off + reflect101(y - ORB_EDGE, L.h)];
+        ymn = min(ymn, (int)(ys & 0xffff));
+        ymx = max(ymx, (int)(ys >> 16));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = min(mn, __shfl_xor(mn, o));
+        mx = max(mx, __shfl_xor(mx, o));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMin(&bounds[0], mn);
+        atomicMax(&bounds[1], mx);
+        if (ybase < yend) {
+            atomicMin(&bounds[2], ymn);
+            atomicMax(&bounds[3], ymx);
+        }
+    }
+    __syncthreads();
+    const int X0 = bounds[0] & ~15;
+    const int nrows = bounds[3] - bounds[2] + 1;
+    const int pc = (bounds[1] - X0 + 16) >> 4;  // 16-byte chunks per staged row
+    const int sy_min = bounds[2];
+    // host sized the LDS for the level's scale; a tile that would not fit reads global memory
+    const bool staged = pc * 16 <= lds_pitch && nrows <= lds_rows;
+    if (staged) {
+        const int nchunk = pc * nrows;
+        const int lp4 = lds_pitch >> 4;
+        for (int i = tid; i < nchunk; i += 256) {
+            const int r = i / pc, k = i - r * pc;
+            rz_lds[r * lp4 + k] = *(const uint4*)(src + (long long)(sy_min + r) * P.stride + X0 + 16 * k);
+        }
+    }
+    __syncthreads();
+    if (!col_ok || ybase >= yend) return;
+    uint8_t* dst = frame + L.plane_off + dwx * 4;
+    const uint32_t* ytab_s = ysrc + L.rz_y_off;
+    const uint32_t* ytab_b = yab + L.rz_y_off;
+    // offsets are formed as non-negative ints and added to the tile / plane origin: no pointer ever
+    // leaves its buffer (LDS pointers are 32-bit and must not wrap)
+    if (staged) {
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            sx[b] -= X0;
+            sx1[b] -= X0;
+        }
+        resize_rows((const uint8_t*)rz_lds, lds_pitch, sy_min, sx, sx1, a0, a1, ytab_s, ytab_b, ybase, yend, L.h, dst,
+                    L.stride, keep);
+    } else {
+        resize_rows(src, P.stride, 0, sx, sx1, a0, a1, ytab_s, ytab_b, ybase, yend, L.h, dst, L.stride, keep);
     }
 }
 
@@ -709,8 +788,15 @@ void launch_level0(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* 
 void launch_resize(hipStream_t st, const GeomDev& hg, int batch, int level, uint8_t* pyr, const GeomDev* dg,
                    const int* xofs, const uint32_t* xab, const uint32_t* ysrc, const uint32_t* yab) {
     const LevelGeom& L = hg.lv[level];
-    dim3 grid((L.stride / 4 + 63) / 64, (L.ph + 4 * RZ_ROWS - 1) / (4 * RZ_ROWS), batch), block(64, 4);
-    hipLaunchKernelGGL(k_resize, grid, block, 0, st, pyr, dg, level, xofs, xab, ysrc, yab);
+    const LevelGeom& P = hg.lv[level - 1];
+    // source rectangle of a 256 x 32 destination tile at this level's scale, plus alignment slack
+    const double sx = (double)P.w / L.w, sy = (double)P.h / L.h;
+    int lds_pitch = ((int)(256 * sx) + 3 + 15 + 15) & ~15;
+    int lds_rows = (int)(RZ_TILE_H * sy) + 4;
+    if ((size_t)lds_pitch * lds_rows > 60 * 1024) lds_rows = (60 * 1024) / lds_pitch;
+    dim3 grid((L.stride / 4 + 63) / 64, (L.ph + RZ_TILE_H - 1) / RZ_TILE_H, batch), block(64, 4);
+    hipLaunchKernelGGL(k_resize, grid, block, (size_t)lds_pitch * lds_rows, st, pyr, dg, level, xofs, xab, ysrc, yab,
+                       lds_pitch, lds_rows);
 }
 
 void launch_score(hipStream_t st, const GeomDev& hg, int batch, int level, const uint8_t* pyr, uint8_t* score,
