@@ -149,6 +149,11 @@ int orbhip_knn2_merge_device(orbhip_matcher* m, const int32_t* d_parts, int nsha
 int orbhip_ratio_test_device(orbhip_matcher* m, const int32_t* d_d1, const int32_t* d_d2, int n,
                              float ratio, int form, int th, uint8_t* d_accept);
 float orbhip_matcher_last_elapsed_ms(orbhip_matcher* m);
+/* Sustained integer-VALU rate of the device in lane-operations per second, measured live with HIP
+ * events over a saturating launch (bench instrumentation; the denominator of the matcher's
+ * roofline): mode 0 = v_bcnt_u32_b32, 1 = the matcher's v_xor_b32 + v_bcnt_u32_b32 mix,
+ * 2 = v_add_u32.  Returns 0 on failure. */
+double orbhip_valu_rate(orbhip_matcher* m, int mode);
 
 /* Device self-tests of the arithmetic helpers (test instrumentation, host pointers, blocking):
  * which 0: n (y, x) float pairs -> n floats, the device's fastAtan2 in degrees

@@ -79,6 +79,8 @@ def lib():
     L.orbhip_ratio_test_device.argtypes = [vp, vp, vp, i32, f32, i32, i32, vp]
     L.orbhip_matcher_last_elapsed_ms.argtypes = [vp]
     L.orbhip_matcher_last_elapsed_ms.restype = f32
+    L.orbhip_valu_rate.argtypes = [vp, i32]
+    L.orbhip_valu_rate.restype = C.c_double
     L.orbhip_extractor_set_profiling.argtypes = [vp, i32]
     L.orbhip_extractor_stage_times.argtypes = [vp, vp, vp]
     L.orbhip_selftest.argtypes = [i32, vp, i32, i32, vp]

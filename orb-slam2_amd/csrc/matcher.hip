@@ -25,16 +25,36 @@ namespace {
 #define KNN_IDX_MASK ((1u << KNN_IDX_BITS) - 1u)
 #define KNN_NONE 0xffffffffu
 
+// popcount(x) + acc in one instruction; the explicit form keeps the 8-word distance a chain of
+// 8 v_xor_b32 + 8 v_bcnt_u32_b32 (the compiler otherwise splits the sum into a tree with extra adds)
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 __device__ __forceinline__ uint32_t ham8(const uint32_t q[8], const uint32_t* __restrict__ t) {
-    uint32_t d = __popc(q[0] ^ t[0]);
-    d += __popc(q[1] ^ t[1]);
-    d += __popc(q[2] ^ t[2]);
-    d += __popc(q[3] ^ t[3]);
-    d += __popc(q[4] ^ t[4]);
-    d += __popc(q[5] ^ t[5]);
-    d += __popc(q[6] ^ t[6]);
-    d += __popc(q[7] ^ t[7]);
+    uint32_t d = bcnt_acc(q[0] ^ t[0], 0u);
+    d = bcnt_acc(q[1] ^ t[1], d);
+    d = bcnt_acc(q[2] ^ t[2], d);
+    d = bcnt_acc(q[3] ^ t[3], d);
+    d = bcnt_acc(q[4] ^ t[4], d);
+    d = bcnt_acc(q[5] ^ t[5], d);
+    d = bcnt_acc(q[6] ^ t[6], d);
+    d = bcnt_acc(q[7] ^ t[7], d);
     return d;
+}
+
+// Folds one candidate key into the running two smallest keys (best <= best2 always holds, so the
+// new second smallest is the median of the three).
+__device__ __forceinline__ void fold_key(uint32_t key, uint32_t& best, uint32_t& best2) {
+    best2 = med3_u32(best, key, best2);
+    best = min(best, key);
 }
 
 // grid: (query blocks of 256, train chunks, pairs).  Each block scans rows [chunk*chunk_rows,
@@ -59,19 +79,12 @@ __global__ __launch_bounds__(256) void k_knn2(const uint32_t* __restrict__ q, in
     const uint32_t* __restrict__ tp = t + (long long)pair * t_pair_words + (long long)j0 * 8;
     uint32_t best = KNN_NONE, best2 = KNN_NONE;
     int j = 0;
-    for (; j + 4 <= rows; j += 4) {
+    for (; j + 8 <= rows; j += 8) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t key = (ham8(qw, tp + (long long)(j + u) * 8) << KNN_IDX_BITS) | (uint32_t)(j + u);
-            best2 = min(best2, max(best, key));
-            best = min(best, key);
-        }
+        for (int u = 0; u < 8; u++)
+            fold_key((ham8(qw, tp + (long long)(j + u) * 8) << KNN_IDX_BITS) | (uint32_t)(j + u), best, best2);
     }
-    for (; j < rows; j++) {
-        const uint32_t key = (ham8(qw, tp + (long long)j * 8) << KNN_IDX_BITS) | (uint32_t)j;
-        best2 = min(best2, max(best, key));
-        best = min(best, key);
-    }
+    for (; j < rows; j++) fold_key((ham8(qw, tp + (long long)j * 8) << KNN_IDX_BITS) | (uint32_t)j, best, best2);
     if (qi >= nq) return;
     if (nchunks == 1) {
         const long long o = (long long)pair * nq + qi;
@@ -148,6 +161,42 @@ __global__ __launch_bounds__(256) void k_ratio(const int32_t* __restrict__ d1, c
     if (form == 0) ok = (float)a < __fmul_rn(ratio, (float)b);
     else ok = (float)a <= __fmul_rn((float)b, ratio);
     accept[i] = (ok && a <= th) ? 1 : 0;
+}
+
+// Micro-benchmarks of the integer VALU instructions the matcher is made of (sustained rate with
+// every CU busy, 8 independent dependency chains per lane).  mode 0: v_bcnt_u32_b32 only,
+// 1: v_xor_b32 + v_bcnt_u32_b32 pairs (the matcher's inner mix), 2: v_add_u32 only.
+__global__ __launch_bounds__(256) void k_valu_rate(uint32_t* out, int iters, int mode, uint32_t seed) {
+    uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    uint32_t x = seed ^ (blockIdx.x * 2654435761u);
+    if (mode == 0) {
+        for (int i = 0; i < iters; i++) {
+            asm volatile(
+                "v_bcnt_u32_b32 %0, %8, %0\n v_bcnt_u32_b32 %1, %8, %1\n v_bcnt_u32_b32 %2, %8, %2\n v_bcnt_u32_b32 %3, %8, %3\n"
+                "v_bcnt_u32_b32 %4, %8, %4\n v_bcnt_u32_b32 %5, %8, %5\n v_bcnt_u32_b32 %6, %8, %6\n v_bcnt_u32_b32 %7, %8, %7\n"
+                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                : "v"(x));
+        }
+    } else if (mode == 1) {
+        uint32_t t0, t1, t2, t3;
+        for (int i = 0; i < iters; i++) {
+            asm volatile(
+                "v_xor_b32 %8, %12, %0\n v_xor_b32 %9, %12, %1\n v_xor_b32 %10, %12, %2\n v_xor_b32 %11, %12, %3\n"
+                "v_bcnt_u32_b32 %4, %8, %4\n v_bcnt_u32_b32 %5, %9, %5\n v_bcnt_u32_b32 %6, %10, %6\n v_bcnt_u32_b32 %7, %11, %7\n"
+                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "=&v"(t0), "=&v"(t1),
+                  "=&v"(t2), "=&v"(t3)
+                : "v"(x));
+        }
+    } else {
+        for (int i = 0; i < iters; i++) {
+            asm volatile(
+                "v_add_u32 %0, %8, %0\n v_add_u32 %1, %8, %1\n v_add_u32 %2, %8, %2\n v_add_u32 %3, %8, %3\n"
+                "v_add_u32 %4, %8, %4\n v_add_u32 %5, %8, %5\n v_add_u32 %6, %8, %6\n v_add_u32 %7, %8, %7\n"
+                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                : "v"(x));
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
 }
 
 #define HIPCHK(call)                                                                         \
@@ -323,6 +372,30 @@ int orbhip_ratio_test_device(orbhip_matcher* m, const int32_t* d_d1, const int32
     hipLaunchKernelGGL(k_ratio, dim3((n + 255) / 256), dim3(256), 0, m->stream, d_d1, d_d2, n, ratio, form, th, d_accept);
     HIPCHK(hipGetLastError());
     return ORBHIP_OK;
+}
+
+// Sustained integer-VALU rate of this device in lane-operations per second (64 lanes x wave
+// instructions), measured with HIP events: mode 0 v_bcnt_u32_b32, 1 the matcher's xor + bcnt mix,
+// 2 v_add_u32.  Returns 0 on failure.
+double orbhip_valu_rate(orbhip_matcher* m, int mode) {
+    if (!m || mode < 0 || mode > 2) return 0.0;
+    if (hipSetDevice(m->device) != hipSuccess) return 0.0;
+    const int blocks = m->sm_count * 32, iters = 4096;
+    uint32_t* d = nullptr;
+    if (hipMalloc(&d, (size_t)blocks * 256 * 4) != hipSuccess) return 0.0;
+    double best = 0.0;
+    for (int rep = 0; rep < 4; rep++) {
+        hipEventRecord(m->ev0, m->stream);
+        hipLaunchKernelGGL(k_valu_rate, dim3(blocks), dim3(256), 0, m->stream, d, iters, mode, 12345u + rep);
+        hipEventRecord(m->ev1, m->stream);
+        if (hipStreamSynchronize(m->stream) != hipSuccess) break;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, m->ev0, m->ev1) != hipSuccess || ms <= 0.f) break;
+        const double ops = (double)blocks * 256 * iters * 8;
+        best = std::max(best, ops / (ms * 1e-3));
+    }
+    hipFree(d);
+    return best;
 }
 
 }  // extern "C"

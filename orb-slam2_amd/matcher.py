@@ -74,6 +74,10 @@ class ORBmatcher:
         r = self.mfNNratio if ratio is None else ratio
         _lib.check(self._L.orbhip_ratio_test_device(self._h, d_d1, d_d2, n, r, form, th, d_accept))
 
+    def valu_rate(self, mode):
+        """Sustained lane-ops/s of v_bcnt (0), the xor+bcnt mix (1) or v_add (2) on this device."""
+        return float(self._L.orbhip_valu_rate(self._h, mode))
+
     def synchronize(self):
         _lib.check(self._L.orbhip_matcher_synchronize(self._h))
 
