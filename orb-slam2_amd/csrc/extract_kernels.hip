@@ -16,6 +16,8 @@
 
 namespace orbk {
 
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+
 __device__ __forceinline__ int reflect101(int p, int n) {
     if (p < 0) p = -p;
     if (p >= n) p = 2 * n - 2 - p;
@@ -35,16 +37,20 @@ __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ imgs
     if (dwx * 4 >= L.stride || y >= L.ph) return;
     const uint8_t* src = imgs + (long long)f * frame_stride;
     const int sy = reflect101(y - ORB_EDGE, L.h);
-    uint32_t out = 0;
+    const uint8_t* srow = src + (long long)sy * row_stride;
+    const int x0 = dwx * 4 - ORB_EDGE;  // source column of the dword's first pixel
+    uint32_t out;
+    if (x0 >= 0 && x0 + 3 < L.w) {
+        out = *(const u32_unaligned*)(srow + x0);  // interior: one (possibly unaligned) dword
+    } else {
+        out = 0;
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-        const int x = dwx * 4 + b;
-        uint32_t v = 0;
-        if (x < L.w + 2 * ORB_EDGE) {
-            const int sx = reflect101(x - ORB_EDGE, L.w);
-            v = src[(long long)sy * row_stride + sx];
+        for (int b = 0; b < 4; b++) {
+            const int x = dwx * 4 + b;
+            uint32_t v = 0;
+            if (x < L.w + 2 * ORB_EDGE) v = srow[reflect101(x - ORB_EDGE, L.w)];
+            out |= v << (8 * b);
         }
-        out |= v << (8 * b);
     }
     *(uint32_t*)(pyr + (long long)f * g->frame_bytes + L.plane_off + (long long)y * L.stride + dwx * 4) = out;
 }
@@ -571,8 +577,6 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 // (u + 16 inside the disc, else 0) and the inside mask, so that with two v_dot4_u32_u8
 //   sum(u * I) = dot4(I, u + 16) - 16 * dot4(I, mask),   sum(v * I) = v * dot4(I, mask).
 // The moments are exact integers whatever the summation order.
-typedef uint32_t u32_unaligned __attribute__((aligned(1)));
-
 __global__ __launch_bounds__(256) void k_orient(const uint8_t* __restrict__ pyr, const GeomDev* __restrict__ g,
                                                 const uint32_t* __restrict__ lvl_list, const int* __restrict__ lvl_count,
                                                 const uint32_t* __restrict__ otab, float* __restrict__ angles) {
@@ -621,6 +625,7 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t* __restrict__ pyr,
 // row loop is fully unrolled so the ring slots are static); per output row the column pass is
 // 7 integer ops per pixel.  No LDS: neighbouring lanes' overlapping loads hit the vector L1.
 #define BL_ROWS 32
+#define BL_PREFETCH 8
 
 __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
                                               const GeomDev* __restrict__ g, int level, int t0, int t1, int t2, int t3) {
@@ -646,41 +651,57 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
         if (px0 + j >= ORB_EDGE && px0 + j < L.w + ORB_EDGE) colmask |= 0xffu << (8 * j);
     uint32_t h[7][4];
     uint32_t ctr[7];
+    const uint32_t* col = (const uint32_t*)src;
+    const int sdw = stride >> 2;
 #pragma unroll
-    for (int i = 0; i < BL_ROWS + 6; i++) {
-        const int yy = min(max(y0 - 3 + i, 0), ph - 1);
-        const uint32_t* row = (const uint32_t*)(src + (long long)yy * stride);
-        const uint32_t a = row[xl], b = row[dwx], c = row[xr];
-        const int slot = i % 7;
-        ctr[slot] = b;
-        // bytes of (a, b, c) are columns px0-4 .. px0+7; pixel j needs byte offsets j+1 .. j+7
-        const uint32_t w1 = __builtin_amdgcn_alignbyte(b, a, 1), w2 = __builtin_amdgcn_alignbyte(b, a, 2);
-        const uint32_t w3 = __builtin_amdgcn_alignbyte(b, a, 3);
-        const uint32_t w5 = __builtin_amdgcn_alignbyte(c, b, 1), w6 = __builtin_amdgcn_alignbyte(c, b, 2);
-        const uint32_t w7 = __builtin_amdgcn_alignbyte(c, b, 3);
-        h[slot][0] = __builtin_amdgcn_udot4(w1, tapsA, __builtin_amdgcn_udot4(w5, tapsB, 0u, false), false);
-        h[slot][1] = __builtin_amdgcn_udot4(w2, tapsA, __builtin_amdgcn_udot4(w6, tapsB, 0u, false), false);
-        h[slot][2] = __builtin_amdgcn_udot4(w3, tapsA, __builtin_amdgcn_udot4(w7, tapsB, 0u, false), false);
-        h[slot][3] = __builtin_amdgcn_udot4(b, tapsA, __builtin_amdgcn_udot4(c, tapsB, 0u, false), false);
-        if (i >= 6) {
-            const int y = y0 + i - 6;
-            if (y < ph) {
-                uint32_t o = ctr[(i - 3) % 7];
-                if (y >= ORB_EDGE && y < L.h + ORB_EDGE && colmask) {
-                    uint32_t bl = 0;
+    for (int c0 = 0; c0 < BL_ROWS + 6; c0 += BL_PREFETCH) {
+        // issue the loads of BL_PREFETCH rows back to back, then do their arithmetic
+        uint32_t ra[BL_PREFETCH], rb[BL_PREFETCH], rc[BL_PREFETCH];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const uint32_t acc = (uint32_t)t0 * (h[(i - 6) % 7][j] + h[i % 7][j]) +
-                                             (uint32_t)t1 * (h[(i - 5) % 7][j] + h[(i - 1) % 7][j]) +
-                                             (uint32_t)t2 * (h[(i - 4) % 7][j] + h[(i - 2) % 7][j]) +
-                                             (uint32_t)t3 * h[(i - 3) % 7][j];
-                        bl |= min((acc + 32768u) >> 16, 255u) << (8 * j);
-                    }
-                    o = (bl & colmask) | (o & ~colmask);
-                }
-                *(uint32_t*)(dst + (long long)y * stride + px0) = o;
+        for (int k = 0; k < BL_PREFETCH; k++)
+            if (c0 + k < BL_ROWS + 6) {
+                const int yy = min(max(y0 - 3 + c0 + k, 0), ph - 1);
+                const uint32_t* row = col + (long long)yy * sdw;
+                ra[k] = row[xl];
+                rb[k] = row[dwx];
+                rc[k] = row[xr];
             }
-        }
+#pragma unroll
+        for (int k = 0; k < BL_PREFETCH; k++)
+            if (c0 + k < BL_ROWS + 6) {
+                const int i = c0 + k;
+                const uint32_t a = ra[k], b = rb[k], c = rc[k];
+                const int slot = i % 7;
+                ctr[slot] = b;
+                // bytes of (a, b, c) are columns px0-4 .. px0+7; pixel j needs byte offsets j+1 .. j+7
+                const uint32_t w1 = __builtin_amdgcn_alignbyte(b, a, 1), w2 = __builtin_amdgcn_alignbyte(b, a, 2);
+                const uint32_t w3 = __builtin_amdgcn_alignbyte(b, a, 3);
+                const uint32_t w5 = __builtin_amdgcn_alignbyte(c, b, 1), w6 = __builtin_amdgcn_alignbyte(c, b, 2);
+                const uint32_t w7 = __builtin_amdgcn_alignbyte(c, b, 3);
+                h[slot][0] = __builtin_amdgcn_udot4(w1, tapsA, __builtin_amdgcn_udot4(w5, tapsB, 0u, false), false);
+                h[slot][1] = __builtin_amdgcn_udot4(w2, tapsA, __builtin_amdgcn_udot4(w6, tapsB, 0u, false), false);
+                h[slot][2] = __builtin_amdgcn_udot4(w3, tapsA, __builtin_amdgcn_udot4(w7, tapsB, 0u, false), false);
+                h[slot][3] = __builtin_amdgcn_udot4(b, tapsA, __builtin_amdgcn_udot4(c, tapsB, 0u, false), false);
+                if (i >= 6) {
+                    const int y = y0 + i - 6;
+                    if (y < ph) {
+                        uint32_t o = ctr[(i - 3) % 7];
+                        if (y >= ORB_EDGE && y < L.h + ORB_EDGE && colmask) {
+                            uint32_t bl = 0;
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const uint32_t acc = (uint32_t)t0 * (h[(i - 6) % 7][j] + h[i % 7][j]) +
+                                                     (uint32_t)t1 * (h[(i - 5) % 7][j] + h[(i - 1) % 7][j]) +
+                                                     (uint32_t)t2 * (h[(i - 4) % 7][j] + h[(i - 2) % 7][j]) +
+                                                     (uint32_t)t3 * h[(i - 3) % 7][j];
+                                bl |= min((acc + 32768u) >> 16, 255u) << (8 * j);
+                            }
+                            o = (bl & colmask) | (o & ~colmask);
+                        }
+                        *(uint32_t*)(dst + (long long)y * stride + px0) = o;
+                    }
+                }
+            }
     }
 }
 

@@ -61,6 +61,10 @@ struct orbhip_extractor {
 
     int device;
     hipStream_t stream = nullptr;
+    // worker streams: a chunk is split into sub-batches whose kernel sequences run concurrently, so
+    // the compute-bound FAST kernel of one sub-batch overlaps the memory-bound stages of another
+    std::vector<hipStream_t> workers;
+    std::vector<hipEvent_t> worker_done;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.f;
     int max_batch;
@@ -314,12 +318,20 @@ int set_size(orbhip_extractor* e, int rows, int cols, int batch) {
 }
 
 // The kernel sequence for `batch` frames whose images, outputs and count array are in device memory.
-int run_chunk(orbhip_extractor* e, const uint8_t* d_imgs, int batch, long long row_stride, long long frame_stride,
-              OrbKeypoint* d_kp, uint8_t* d_desc, int cap, int* d_n) {
+// `slot0` is the arena slot of the first frame; all per-frame arenas are offset by it.
+int run_chunk(orbhip_extractor* e, hipStream_t st, int slot0, const uint8_t* d_imgs, int batch, long long row_stride,
+              long long frame_stride, OrbKeypoint* d_kp, uint8_t* d_desc, int cap, int* d_n) {
     const GeomDev& g = e->hg;
     const GeomDev* dg = e->d_geom.as<GeomDev>();
-    hipStream_t st = e->stream;
-    uint8_t* pyr = e->d_pyr.as<uint8_t>();
+    uint8_t* pyr = e->d_pyr.as<uint8_t>() + (size_t)slot0 * g.frame_bytes;
+    uint8_t* blur = e->d_blur.as<uint8_t>() + (size_t)slot0 * g.frame_bytes;
+    uint8_t* score = e->fused_fast ? nullptr : e->d_score.as<uint8_t>() + (size_t)slot0 * g.frame_bytes;
+    uint32_t* cand = e->d_cand.as<uint32_t>() + (size_t)slot0 * g.cand_per_frame;
+    int* ntotal = e->d_ntotal.as<int>() + (size_t)slot0 * g.cells_per_frame;
+    int* nretain = e->d_nretain.as<int>() + (size_t)slot0 * g.cells_per_frame;
+    uint32_t* lvl = e->d_lvl.as<uint32_t>() + (size_t)slot0 * g.lvl_per_frame;
+    int* lvlcount = e->d_lvlcount.as<int>() + (size_t)slot0 * g.nlevels;
+    float* angles = e->d_angles.as<float>() + (size_t)slot0 * g.nfeatures;
     hipEvent_t* pev = nullptr;
     if (e->profiling) {
         const size_t need = (size_t)(e->prof_chunks + 1) * (ORB_NSTAGES + 1);
@@ -340,29 +352,25 @@ int run_chunk(orbhip_extractor* e, const uint8_t* d_imgs, int batch, long long r
                             e->d_ysrc.as<uint32_t>(), e->d_yab.as<uint32_t>());
     STAGE_MARK(2);
     if (!e->fused_fast)
-        for (int l = 0; l < g.nlevels; l++) orbk::launch_score(st, g, batch, l, pyr, e->d_score.as<uint8_t>(), dg);
+        for (int l = 0; l < g.nlevels; l++) orbk::launch_score(st, g, batch, l, pyr, score, dg);
     STAGE_MARK(3);
     if (e->fused_fast)
-        orbk::launch_fast_cell(st, g, batch, e->max_cell_w, e->max_cell_h, pyr, dg, e->d_cells.as<CellDesc>(),
-                               e->d_cand.as<uint32_t>(), e->d_ntotal.as<int>(), e->d_err.as<int>());
+        orbk::launch_fast_cell(st, g, batch, e->max_cell_w, e->max_cell_h, pyr, dg, e->d_cells.as<CellDesc>(), cand, ntotal,
+                               e->d_err.as<int>());
     else
-        orbk::launch_nms(st, g, batch, e->max_cell_h, e->d_score.as<uint8_t>(), dg, e->d_cells.as<CellDesc>(),
-                         e->d_cand.as<uint32_t>(), e->d_ntotal.as<int>(), e->d_err.as<int>());
+        orbk::launch_nms(st, g, batch, e->max_cell_h, score, dg, e->d_cells.as<CellDesc>(), cand, ntotal, e->d_err.as<int>());
     STAGE_MARK(4);
-    orbk::launch_select(st, g, batch, dg, e->d_cells.as<CellDesc>(), e->d_cand.as<uint32_t>(), e->d_ntotal.as<int>(),
-                        e->d_nretain.as<int>(), e->d_lvl.as<uint32_t>(), e->d_lvlcount.as<int>(), e->d_err.as<int>());
+    orbk::launch_select(st, g, batch, dg, e->d_cells.as<CellDesc>(), cand, ntotal, nretain, lvl, lvlcount, e->d_err.as<int>());
     STAGE_MARK(5);
-    orbk::launch_orient(st, g, batch, pyr, dg, e->d_lvl.as<uint32_t>(), e->d_lvlcount.as<int>(), e->d_disc.as<uint32_t>(),
-                        e->d_angles.as<float>());
+    orbk::launch_orient(st, g, batch, pyr, dg, lvl, lvlcount, e->d_disc.as<uint32_t>(), angles);
     STAGE_MARK(6);
-    for (int l = 0; l < g.nlevels; l++) orbk::launch_blur(st, g, batch, l, pyr, e->d_blur.as<uint8_t>(), dg, e->gtaps);
+    for (int l = 0; l < g.nlevels; l++) orbk::launch_blur(st, g, batch, l, pyr, blur, dg, e->gtaps);
     STAGE_MARK(7);
-    orbk::launch_describe(st, g, batch, e->d_blur.as<uint8_t>(), dg, e->d_lvl.as<uint32_t>(), e->d_lvlcount.as<int>(),
-                          e->d_angles.as<float>(), e->d_pattern.as<int8_t>(), (OrbKeypointDev*)d_kp, d_desc, d_n, cap);
+    orbk::launch_describe(st, g, batch, blur, dg, lvl, lvlcount, angles, e->d_pattern.as<int8_t>(), (OrbKeypointDev*)d_kp,
+                          d_desc, d_n, cap);
     STAGE_MARK(8);
 #undef STAGE_MARK
     HIPCHK(hipGetLastError());
-    e->last_batch = batch;
     return ORBHIP_OK;
 }
 
@@ -415,6 +423,26 @@ int orbhip_extractor_create(orbhip_extractor** out, int nfeatures, float scale_f
             rc = orb_fail(ORBHIP_EHIP, "stream/event creation failed");
             break;
         }
+        {
+            const char* env = getenv("ORBHIP_STREAMS");
+            int nw = env ? atoi(env) : 4;
+            nw = std::max(1, std::min(nw, 16));
+            bool ok = true;
+            for (int i = 0; i < nw && ok; i++) {
+                hipStream_t st;
+                ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+                if (ok) e->workers.push_back(st);
+            }
+            for (int i = 0; i < nw + 1 && ok; i++) {
+                hipEvent_t ev;
+                ok = hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+                if (ok) e->worker_done.push_back(ev);
+            }
+            if (!ok) {
+                rc = orb_fail(ORBHIP_EHIP, "worker stream creation failed");
+                break;
+            }
+        }
         // orientation table: per (disc row v, dword j) the byte weights u + 16 (0 outside the disc) and
         // the inside mask of the four pixels u = -15 + 4j .. -12 + 4j
         std::vector<uint32_t> otab(2 * 256, 0u);
@@ -464,6 +492,8 @@ void orbhip_extractor_destroy(orbhip_extractor* e) {
                          &e->d_lvlcount, &e->d_angles, &e->d_err, &e->d_img, &e->d_kp, &e->d_desc, &e->d_n};
     for (DeviceBuf* b : bufs) b->release();
     for (hipEvent_t ev : e->prof_ev) hipEventDestroy(ev);
+    for (hipEvent_t ev : e->worker_done) hipEventDestroy(ev);
+    for (hipStream_t st : e->workers) hipStreamDestroy(st);
     if (e->ev0) hipEventDestroy(e->ev0);
     if (e->ev1) hipEventDestroy(e->ev1);
     if (e->stream) hipStreamDestroy(e->stream);
@@ -500,9 +530,28 @@ int orbhip_extract_batch_device(orbhip_extractor* e, const uint8_t* d_imgs, int 
     HIPCHK(hipEventRecord(e->ev0, e->stream));
     for (int f0 = 0; f0 < batch; f0 += chunk) {
         const int b = std::min(chunk, batch - f0);
-        rc = run_chunk(e, d_imgs + (long long)f0 * frame_stride, b, row_stride, frame_stride, d_kp_out + (long long)f0 * cap,
-                       d_desc_out + (long long)f0 * cap * 32, cap, d_n_out + f0);
-        if (rc) return rc;
+        // sub-batches on the worker streams (single stream while per-stage timing is on, or for tiny chunks)
+        const int nsub = e->profiling ? 1 : std::max(1, std::min<int>((int)e->workers.size(), b / 8));
+        if (nsub == 1) {
+            rc = run_chunk(e, e->stream, 0, d_imgs + (long long)f0 * frame_stride, b, row_stride, frame_stride,
+                           d_kp_out + (long long)f0 * cap, d_desc_out + (long long)f0 * cap * 32, cap, d_n_out + f0);
+            if (rc) return rc;
+        } else {
+            hipEvent_t start = e->worker_done[nsub];  // spare event: the chunk may start once earlier work is done
+            HIPCHK(hipEventRecord(start, e->stream));
+            for (int sub = 0; sub < nsub; sub++) {
+                const int s0 = (int)((long long)b * sub / nsub), s1 = (int)((long long)b * (sub + 1) / nsub);
+                hipStream_t st = e->workers[sub];
+                HIPCHK(hipStreamWaitEvent(st, start, 0));
+                rc = run_chunk(e, st, s0, d_imgs + (long long)(f0 + s0) * frame_stride, s1 - s0, row_stride, frame_stride,
+                               d_kp_out + (long long)(f0 + s0) * cap, d_desc_out + (long long)(f0 + s0) * cap * 32, cap,
+                               d_n_out + f0 + s0);
+                if (rc) return rc;
+                HIPCHK(hipEventRecord(e->worker_done[sub], st));
+                HIPCHK(hipStreamWaitEvent(e->stream, e->worker_done[sub], 0));
+            }
+        }
+        e->last_batch = b;
     }
     HIPCHK(hipEventRecord(e->ev1, e->stream));
     return ORBHIP_OK;

@@ -3,12 +3,11 @@
 // threshold 7 when that found <= 3 keypoints — entirely out of LDS:
 //
 //   1. the cell image (examined pixels + 3-px halo) is staged into LDS with aligned 16-byte loads;
-//   2. QUICK TEST (all waves, 16 rows per round): every examined pixel is tested on the four compass
+//   2. QUICK TEST (every wave on its own rows): every examined pixel is tested on the four compass
 //      pixels of the Bresenham circle (a 9-arc always contains one of {0,8} and one of {4,12}), a
 //      necessary condition for a corner at the threshold of the pass, two pixels per packed 16-bit
-//      instruction; survivors are appended to a block-wide list (ballot prefix + one LDS atomic
-//      per wave);
-//   3. MEASURE (all waves share the list, dense lanes): the exact corner measure M = max(A, B)
+//      instruction; survivors are appended to the wave's own list (ballot prefix sums);
+//   3. MEASURE (whole 64-entry chunks of the wave's list, dense lanes): the exact corner measure M = max(A, B)
 //      (fast_measure.h) of each listed pixel goes to an LDS score tile that is zero elsewhere;
 //      pixels with M above the threshold are appended to a corner list;
 //   4. NMS over the corner list: a pixel is a keypoint at threshold t iff M > t and M is a strict
@@ -33,8 +32,8 @@ namespace orbk {
 
 #define FC_THREADS 512
 #define FC_WAVES (FC_THREADS / 64)
-#define FC_RBLK 16            // rows per quick-test round
-#define FC_QCAP (FC_RBLK * 256)
+#define FC_WCAP (2 * 256 + 64)  // per-wave list: survivors of two rows + a carried-over partial chunk
+#define FC_QCAP (FC_WAVES * FC_WCAP)
 
 typedef short short2v __attribute__((ext_vector_type(2)));
 
@@ -83,7 +82,6 @@ __global__ __launch_bounds__(FC_THREADS) void k_fast_cell(const uint8_t* __restr
                                                           const CellDesc* __restrict__ cells, uint32_t* __restrict__ cand,
                                                           int* __restrict__ n_total, int* __restrict__ err, int ccap) {
     extern __shared__ uint4 lds4[];
-    __shared__ int qn[2];
     __shared__ int cn;
     __shared__ int red[FC_WAVES];
     const int c = blockIdx.x, f = blockIdx.y;
@@ -146,66 +144,58 @@ __global__ __launch_bounds__(FC_THREADS) void k_fast_cell(const uint8_t* __restr
         uint32_t* z32 = (uint32_t*)scb;  // score tile and bitmap are contiguous
         const int nz = (int)((uint32_t*)qlist - z32);
         for (int i = tid; i < nz; i += FC_THREADS) z32[i] = 0;
-        if (tid == 0) {
-            qn[0] = 0;
-            qn[1] = 0;
-            cn = 0;
-        }
+        if (tid == 0) cn = 0;
     }
     __syncthreads();
     const short2v thr1 = {(short)(t + 1), (short)(t + 1)};
     const short2v nthr1 = {(short)(-t - 1), (short)(-t - 1)};
 
-    // ---- quick test + exact measure, FC_RBLK rows per round -----------------------------------------
-    int par = 0;
-    for (int rb = 0; rb < ch; rb += FC_RBLK, par ^= 1) {
-        // each wave tests two rows of the round
-        const int ra = rb + wave, rb2 = rb + wave + FC_WAVES;
-        const bool hasA = ra < ch, hasB = rb2 < ch && wave + FC_WAVES < FC_RBLK;
+    // ---- quick test + exact measure: every wave works through its own rows and its own list, no
+    // block barrier until all rows are done.  A wave tests two rows, appends the survivors to its
+    // list and then measures whole chunks of 64 entries taken from the end of the list, so the
+    // measure always runs with all lanes busy; what is left (< 64 entries) waits for the next rows.
+    uint16_t* wl = qlist + wave * FC_WCAP;
+    int n = 0;
+    for (int ra = 2 * wave; ra < ch; ra += 2 * FC_WAVES) {
+        const int rb2 = ra + 1;
         uint32_t za0 = 0xffffffffu, za1 = 0xffffffffu, zb0 = 0xffffffffu, zb1 = 0xffffffffu;
-        if (act && hasA) quick_row(imgb, pitch, gg, ra, thr1, nthr1, za0, za1);
-        if (act && hasB) quick_row(imgb, pitch, gg, rb2, thr1, nthr1, zb0, zb1);
+        if (act) quick_row(imgb, pitch, gg, ra, thr1, nthr1, za0, za1);
+        if (act && rb2 < ch) quick_row(imgb, pitch, gg, rb2, thr1, nthr1, zb0, zb1);
         // per-lane pass nibbles (bit j = pixel j of the group passes and is an examined pixel)
         const uint32_t nibA = ~(((za0 >> 15) & 1u) | ((za0 >> 30) & 2u) | ((za1 >> 13) & 4u) | ((za1 >> 28) & 8u)) & vnib;
         const uint32_t nibB = ~(((zb0 >> 15) & 1u) | ((zb0 >> 30) & 2u) | ((zb1 >> 13) & 4u) | ((zb1 >> 28) & 8u)) & vnib;
-        // lane offsets inside the wave's block of entries: pixels of lower lanes come first
-        int before = 0, totA = 0, totB = 0;
+        int beforeA = 0, beforeB = 0, totA = 0, totB = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const unsigned long long ma = __ballot((nibA >> j) & 1u), mb = __ballot((nibB >> j) & 1u);
-            before += lane_prefix(ma);
+            beforeA += lane_prefix(ma);
+            beforeB += lane_prefix(mb);
             totA += __popcll(ma);
             totB += __popcll(mb);
         }
-        int beforeB = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) beforeB += lane_prefix(__ballot((nibB >> j) & 1u));
-        int base = 0;
-        if (lane == 0 && totA + totB > 0) base = atomicAdd(&qn[par], totA + totB);
-        base = __builtin_amdgcn_readfirstlane(base);
         {
-            int pos = base + before;
+            int pos = n + beforeA;
             const uint32_t e = (uint32_t)(ra << 8) | (uint32_t)(4 * gg);
 #pragma unroll
             for (int j = 0; j < 4; j++)
-                if ((nibA >> j) & 1u) qlist[pos++] = (uint16_t)(e + j);
+                if ((nibA >> j) & 1u) wl[pos++] = (uint16_t)(e + j);
         }
         {
-            int pos = base + totA + beforeB;
+            int pos = n + totA + beforeB;
             const uint32_t e = (uint32_t)(rb2 << 8) | (uint32_t)(4 * gg);
 #pragma unroll
             for (int j = 0; j < 4; j++)
-                if ((nibB >> j) & 1u) qlist[pos++] = (uint16_t)(e + j);
+                if ((nibB >> j) & 1u) wl[pos++] = (uint16_t)(e + j);
         }
-        __syncthreads();
-        const int n = qn[par];
-        if (tid == 0) qn[par ^ 1] = 0;
-        for (int i0 = 0; i0 < n; i0 += FC_THREADS) {
-            const int i = i0 + tid;
+        n += totA + totB;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const bool last = ra + 2 * FC_WAVES >= ch;
+        while (n >= 64 || (last && n > 0)) {
+            const int i = n - 64 + lane;  // the last (partial) chunk leaves the low lanes idle
             uint32_t e = 0;
             int m = 0;
-            if (i < n) {
-                e = qlist[i];
+            if (i >= 0) {
+                e = wl[i];
                 m = min(fast_measure_tile(imgb + ((e >> 8) + 3) * pitch + (e & 255), pitch), 255);
             }
             const bool corner = m > t;
@@ -218,9 +208,10 @@ __global__ __launch_bounds__(FC_THREADS) void k_fast_cell(const uint8_t* __restr
                 const int pos = cbase + lane_prefix(mask);
                 if (pos < ccap) clist[pos] = (uint16_t)e;
             }
+            n = max(n - 64, 0);
         }
-        __syncthreads();
     }
+    __syncthreads();
 
     // ---- strict-maximum NMS into the bitmap --------------------------------------------------------
     const int ncorner = cn;
