@@ -25,13 +25,13 @@ void launch_fast_cell(hipStream_t st, const GeomDev& hg, int batch, int max_cw, 
                       const GeomDev* dg, const CellDesc* cells, uint32_t* cand, int* n_total, int* err);
 void launch_select(hipStream_t st, const GeomDev& hg, int batch, const GeomDev* dg, const CellDesc* cells,
                    uint32_t* cand, const int* n_total, int* n_retain, uint32_t* lvl_list, int* lvl_count, int* err);
-void launch_orient(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* pyr, const GeomDev* dg,
-                   const uint32_t* lvl_list, const int* lvl_count, const uint32_t* otab, float* angles);
 void launch_blur(hipStream_t st, const GeomDev& hg, int batch, int level, const uint8_t* pyr, uint8_t* blur,
                  const GeomDev* dg, const int taps[7]);
-void launch_describe(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* blur, const GeomDev* dg,
-                     const uint32_t* lvl_list, const int* lvl_count, const float* angles, const int8_t* pattern,
-                     OrbKeypointDev* kp_out, uint8_t* desc_out, int* n_out, int cap);
+// IC_Angle + computeOrbDescriptor + output records, one half-wave per keypoint.
+void launch_orient_describe(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* pyr, const uint8_t* blur,
+                            const GeomDev* dg, const uint32_t* lvl_list, const int* lvl_count, const uint32_t* otab,
+                            float* angles, const int8_t* pattern, OrbKeypointDev* kp_out, uint8_t* desc_out, int* n_out,
+                            int cap);
 void launch_test_atan2(hipStream_t st, const float* yx, float* out, int n);
 void launch_test_sincos(hipStream_t st, const float* in, float* out, int n);
 void launch_test_select(hipStream_t st, uint32_t* keys, int n, int nth);

@@ -115,9 +115,10 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, const
     const LevelGeom& L = g->lv[level];
     const LevelGeom& P = g->lv[level - 1];
     const int tid = threadIdx.y * 64 + threadIdx.x;
-    const int dwx = blockIdx.x * 64 + threadIdx.x;
-    const int ybase = (blockIdx.y * 4 + threadIdx.y) * RZ_ROWS;
-    const int f = blockIdx.z;
+    int bx, by, f;
+    xcd_frame_swizzle3(bx, by, f);
+    const int dwx = bx * 64 + threadIdx.x;
+    const int ybase = (by * 4 + threadIdx.y) * RZ_ROWS;
     uint8_t* frame = pyr + (long long)f * g->frame_bytes;
     const uint8_t* src = frame + P.plane_off + (long long)ORB_EDGE * P.stride + ORB_EDGE;
     const bool col_ok = dwx * 4 < L.stride;
@@ -571,47 +572,6 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
-// IC_Angle (src/ORBextractor.cc:124-151): intensity-centroid moments over the radius-15 disc of
-// the UNBLURRED level image, one wave per keypoint.  The 31 disc rows are covered by 31 x 8
-// (unaligned) dword loads, four pixels each; a host-built table gives, per dword, the byte weights
-// (u + 16 inside the disc, else 0) and the inside mask, so that with two v_dot4_u32_u8
-//   sum(u * I) = dot4(I, u + 16) - 16 * dot4(I, mask),   sum(v * I) = v * dot4(I, mask).
-// The moments are exact integers whatever the summation order.
-__global__ __launch_bounds__(256) void k_orient(const uint8_t* __restrict__ pyr, const GeomDev* __restrict__ g,
-                                                const uint32_t* __restrict__ lvl_list, const int* __restrict__ lvl_count,
-                                                const uint32_t* __restrict__ otab, float* __restrict__ angles) {
-    const int f = blockIdx.y;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    int level, k, oi;
-    uint32_t key;
-    if (!slot_to_key(g, lvl_list, lvl_count, f, slot, level, k, key, oi)) return;
-    const LevelGeom& L = g->lv[level];
-    const int x = key & 0xfff, y = (key >> 12) & 0xfff;
-    const int stride = L.stride;
-    const uint8_t* center = pyr + (long long)f * g->frame_bytes + L.plane_off + (long long)(y + ORB_EDGE) * stride + (x + ORB_EDGE);
-    int m10 = 0, m01 = 0;
-#pragma unroll
-    for (int it = 0; it < 4; it++) {
-        const int idx = it * 64 + lane;
-        if (idx < 31 * 8) {
-            const int v = (idx >> 3) - ORB_HALF_PATCH;
-            const uint32_t I = *(const u32_unaligned*)(center + v * stride - ORB_HALF_PATCH + 4 * (idx & 7));
-            const uint2 w = ((const uint2*)otab)[idx];
-            const int s = (int)__builtin_amdgcn_udot4(I, w.y, 0u, false);
-            const int t = (int)__builtin_amdgcn_udot4(I, w.x, 0u, false);
-            m10 += t - 16 * s;
-            m01 += v * s;
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        m10 += __shfl_xor(m10, o);
-        m01 += __shfl_xor(m01, o);
-    }
-    if (lane == 0) angles[(long long)f * g->nfeatures + slot] = fast_atan2_deg((float)m01, (float)m10);
-}
-
 // ---------------------------------------------------------------------------------------------
 // GaussianBlur(level, level, Size(7,7), 2, 2, BORDER_REFLECT_101) on the level ROI
 // (src/ORBextractor.cc:760): separable integer taps [18,34,49,55,49,34,18], row pass in int32,
@@ -630,10 +590,11 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t* __restrict__ pyr,
 __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
                                               const GeomDev* __restrict__ g, int level, int t0, int t1, int t2, int t3) {
     const LevelGeom& L = g->lv[level];
-    const int f = blockIdx.z;
+    int bx, by, f;
+    xcd_frame_swizzle3(bx, by, f);
     const int ndw = L.stride >> 2;
-    const int dwx = blockIdx.x * 64 + threadIdx.x;
-    const int y0 = (blockIdx.y * 4 + threadIdx.y) * BL_ROWS;
+    const int dwx = bx * 64 + threadIdx.x;
+    const int y0 = (by * 4 + threadIdx.y) * BL_ROWS;
     const int ph = L.ph;
     if (dwx >= ndw || y0 >= ph) return;
     const long long base = (long long)f * g->frame_bytes + L.plane_off;
@@ -706,15 +667,39 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
 }
 
 // ---------------------------------------------------------------------------------------------
-// computeOrbDescriptor (src/ORBextractor.cc:154-194) on the blurred plane + the output record of
-// operator() (:769-777).  32 lanes per keypoint, lane i produces descriptor byte i (8 tests).
-__global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ blur, const GeomDev* __restrict__ g,
-                                                  const uint32_t* __restrict__ lvl_list, const int* __restrict__ lvl_count,
-                                                  const float* __restrict__ angles, const int8_t* __restrict__ pattern,
-                                                  OrbKeypointDev* __restrict__ kp_out, uint8_t* __restrict__ desc_out,
-                                                  int* __restrict__ n_out, int cap) {
-    const int f = blockIdx.y;
-    const int slot = blockIdx.x * 8 + (threadIdx.x >> 5);
+// IC_Angle (src/ORBextractor.cc:124-151) + computeOrbDescriptor (:154-194) + the output record of
+// operator() (:769-777) in one kernel, 32 lanes (half a wave) per keypoint, so that the chain of
+// dependent memory round trips (level counts -> key -> pixels) is paid once per keypoint.
+//
+// Orientation: intensity-centroid moments over the radius-15 disc of the UNBLURRED level image.
+// The 31 disc rows are covered by 31 x 8 (unaligned) dword loads, four pixels each; a host-built
+// table gives, per dword, the byte weights (u + 16 inside the disc, else 0) and the inside mask,
+// so that with two v_dot4_u32_u8
+//   sum(u * I) = dot4(I, u + 16) - 16 * dot4(I, mask),   sum(v * I) = v * dot4(I, mask).
+// The moments are exact integers whatever the summation order.
+//
+// Descriptor: lane i produces descriptor byte i (8 tests) from the BLURRED plane.  The rotated
+// pattern reaches at most 18 px from the keypoint (largest pattern radius 18.38), so the 37 x 37
+// window around it is copied to LDS with row-contiguous dword loads (37 rows of 10 unaligned
+// dwords) and the 16 scattered samples of each lane are LDS byte reads; gathering them from
+// global memory instead costs one vector-cache tag lookup per lane and sample.
+#define DS_REACH 18
+#define DS_ROWS (2 * DS_REACH + 1)
+#define DS_DWORDS 10  // 37 bytes from an arbitrary byte address, rounded up to dwords
+#define DS_ITERS ((DS_ROWS * DS_DWORDS + 31) / 32)
+
+__global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
+                                                         const GeomDev* __restrict__ g,
+                                                         const uint32_t* __restrict__ lvl_list,
+                                                         const int* __restrict__ lvl_count,
+                                                         const uint32_t* __restrict__ otab, float* __restrict__ angles,
+                                                         const int8_t* __restrict__ pattern,
+                                                         OrbKeypointDev* __restrict__ kp_out, uint8_t* __restrict__ desc_out,
+                                                         int* __restrict__ n_out, int cap) {
+    __shared__ uint32_t ds_win[8][DS_ROWS * DS_DWORDS];
+    int bx = blockIdx.x, f = blockIdx.y;
+    xcd_frame_swizzle(bx, f, (int)gridDim.x, (int)gridDim.y);
+    const int slot = bx * 8 + (threadIdx.x >> 5);
     const int li = threadIdx.x & 31;
     if (slot == 0 && li == 0) {
         int n = 0;
@@ -724,15 +709,61 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ bl
     int level, k, oi;
     uint32_t key;
     if (!slot_to_key(g, lvl_list, lvl_count, f, slot, level, k, key, oi)) return;
-    if (oi >= cap) return;
     const LevelGeom& L = g->lv[level];
     const int x = key & 0xfff, y = (key >> 12) & 0xfff;
-    const float angle_deg = angles[(long long)f * g->nfeatures + slot];
+    const int stride = L.stride;
+    const long long pix = (long long)f * g->frame_bytes + L.plane_off + (long long)(y + ORB_EDGE) * stride + (x + ORB_EDGE);
+
+    // all loads of both windows are issued before anything waits on them
+    const uint8_t* ocenter = pyr + pix;
+    uint32_t disc[8];
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int idx = min(it * 32 + li, 31 * 8 - 1);
+        disc[it] = *(const u32_unaligned*)(ocenter + ((idx >> 3) - ORB_HALF_PATCH) * stride - ORB_HALF_PATCH + 4 * (idx & 7));
+    }
+    const uint8_t* corner = blur + pix - (long long)DS_REACH * stride - DS_REACH;
+    uint32_t wreg[DS_ITERS];
+#pragma unroll
+    for (int it = 0; it < DS_ITERS; it++) {
+        const int i = min(it * 32 + li, DS_ROWS * DS_DWORDS - 1);
+        const int r = i / DS_DWORDS, cdw = i - r * DS_DWORDS;
+        wreg[it] = *(const u32_unaligned*)(corner + r * stride + 4 * cdw);
+    }
+
+    int m10 = 0, m01 = 0;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int idx = it * 32 + li;
+        if (idx < 31 * 8) {
+            const int v = (idx >> 3) - ORB_HALF_PATCH;
+            const uint2 w = ((const uint2*)otab)[idx];
+            const int s = (int)__builtin_amdgcn_udot4(disc[it], w.y, 0u, false);
+            const int t = (int)__builtin_amdgcn_udot4(disc[it], w.x, 0u, false);
+            m10 += t - 16 * s;
+            m01 += v * s;
+        }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+        m10 += __shfl_xor(m10, o);
+        m01 += __shfl_xor(m01, o);
+    }
+    const float angle_deg = fast_atan2_deg((float)m01, (float)m10);
+    if (li == 0) angles[(long long)f * g->nfeatures + slot] = angle_deg;
+
+    uint32_t* win = ds_win[threadIdx.x >> 5];
+#pragma unroll
+    for (int it = 0; it < DS_ITERS; it++) {
+        const int i = it * 32 + li;
+        if (i < DS_ROWS * DS_DWORDS) win[i] = wreg[it];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the window is private to this half-wave
+
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float angle = angle_deg * factorPI;
     const float a = orbtrig::cos_f<false>(angle), b = orbtrig::sin_f<false>(angle);
-    const int stride = L.stride;
-    const uint8_t* center = blur + (long long)f * g->frame_bytes + L.plane_off + (long long)(y + ORB_EDGE) * stride + (x + ORB_EDGE);
+    const uint8_t* center = (const uint8_t*)win + DS_REACH * (4 * DS_DWORDS) + DS_REACH;
     const int8_t* pat = pattern + li * 32;
     uint32_t val = 0;
 #pragma unroll
@@ -742,9 +773,10 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t* __restrict__ bl
         const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
         const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int v0 = center[r0 * stride + c0], v1 = center[r1 * stride + c1];
+        const int v0 = center[r0 * (4 * DS_DWORDS) + c0], v1 = center[r1 * (4 * DS_DWORDS) + c1];
         val |= (uint32_t)(v0 < v1) << j;
     }
+    if (oi >= cap) return;
     const long long o = (long long)f * cap + oi;
     desc_out[o * 32 + li] = (uint8_t)val;
     if (li < 7) {
@@ -842,12 +874,6 @@ void launch_select(hipStream_t st, const GeomDev& hg, int batch, const GeomDev* 
     hipLaunchKernelGGL(k_select, grid, block, 0, st, dg, cells, cand, n_total, n_retain, lvl_list, lvl_count, err);
 }
 
-void launch_orient(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* pyr, const GeomDev* dg,
-                   const uint32_t* lvl_list, const int* lvl_count, const uint32_t* otab, float* angles) {
-    dim3 grid((hg.nfeatures + 3) / 4, batch), block(256);
-    hipLaunchKernelGGL(k_orient, grid, block, 0, st, pyr, dg, lvl_list, lvl_count, otab, angles);
-}
-
 void launch_blur(hipStream_t st, const GeomDev& hg, int batch, int level, const uint8_t* pyr, uint8_t* blur,
                  const GeomDev* dg, const int taps[7]) {
     const LevelGeom& L = hg.lv[level];
@@ -855,12 +881,13 @@ void launch_blur(hipStream_t st, const GeomDev& hg, int batch, int level, const 
     hipLaunchKernelGGL(k_blur, grid, block, 0, st, pyr, blur, dg, level, taps[0], taps[1], taps[2], taps[3]);
 }
 
-void launch_describe(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* blur, const GeomDev* dg,
-                     const uint32_t* lvl_list, const int* lvl_count, const float* angles, const int8_t* pattern,
-                     OrbKeypointDev* kp_out, uint8_t* desc_out, int* n_out, int cap) {
+void launch_orient_describe(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* pyr, const uint8_t* blur,
+                            const GeomDev* dg, const uint32_t* lvl_list, const int* lvl_count, const uint32_t* otab,
+                            float* angles, const int8_t* pattern, OrbKeypointDev* kp_out, uint8_t* desc_out, int* n_out,
+                            int cap) {
     dim3 grid((hg.nfeatures + 7) / 8, batch), block(256);
-    hipLaunchKernelGGL(k_describe, grid, block, 0, st, blur, dg, lvl_list, lvl_count, angles, pattern, kp_out, desc_out,
-                       n_out, cap);
+    hipLaunchKernelGGL(k_orient_describe, grid, block, 0, st, pyr, blur, dg, lvl_list, lvl_count, otab, angles, pattern,
+                       kp_out, desc_out, n_out, cap);
 }
 
 void launch_test_atan2(hipStream_t st, const float* yx, float* out, int n) {

@@ -362,12 +362,11 @@ int run_chunk(orbhip_extractor* e, hipStream_t st, int slot0, const uint8_t* d_i
     STAGE_MARK(4);
     orbk::launch_select(st, g, batch, dg, e->d_cells.as<CellDesc>(), cand, ntotal, nretain, lvl, lvlcount, e->d_err.as<int>());
     STAGE_MARK(5);
-    orbk::launch_orient(st, g, batch, pyr, dg, lvl, lvlcount, e->d_disc.as<uint32_t>(), angles);
-    STAGE_MARK(6);
+    STAGE_MARK(6);  // the orientation is computed by the descriptor kernel
     for (int l = 0; l < g.nlevels; l++) orbk::launch_blur(st, g, batch, l, pyr, blur, dg, e->gtaps);
     STAGE_MARK(7);
-    orbk::launch_describe(st, g, batch, blur, dg, lvl, lvlcount, angles, e->d_pattern.as<int8_t>(), (OrbKeypointDev*)d_kp,
-                          d_desc, d_n, cap);
+    orbk::launch_orient_describe(st, g, batch, pyr, blur, dg, lvl, lvlcount, e->d_disc.as<uint32_t>(), angles,
+                                 e->d_pattern.as<int8_t>(), (OrbKeypointDev*)d_kp, d_desc, d_n, cap);
     STAGE_MARK(8);
 #undef STAGE_MARK
     HIPCHK(hipGetLastError());
@@ -527,6 +526,7 @@ int orbhip_extract_batch_device(orbhip_extractor* e, const uint8_t* d_imgs, int 
     const int chunk = std::min(batch, e->max_batch);
     if ((rc = set_size(e, rows, cols, chunk))) return rc;
     e->prof_chunks = 0;
+    (void)hipGetLastError();  // a stale error of an earlier, unrelated call must not be charged to these launches
     HIPCHK(hipEventRecord(e->ev0, e->stream));
     for (int f0 = 0; f0 < batch; f0 += chunk) {
         const int b = std::min(chunk, batch - f0);
@@ -561,10 +561,13 @@ int orbhip_extractor_synchronize(orbhip_extractor* e) {
     if (!e) return orb_fail(ORBHIP_EINVAL, "null extractor");
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
-    if (hipEventElapsedTime(&e->last_ms, e->ev0, e->ev1) != hipSuccess) e->last_ms = 0.f;
+    if (hipEventElapsedTime(&e->last_ms, e->ev0, e->ev1) != hipSuccess) {
+        e->last_ms = 0.f;
+        (void)hipGetLastError();
+    }
     if (e->profiling) {
         const int nl = e->nlevels;
-        const int per_chunk[ORB_NSTAGES] = {1, nl - 1, e->fused_fast ? 0 : nl, 1, 1, 1, nl, 1};
+        const int per_chunk[ORB_NSTAGES] = {1, nl - 1, e->fused_fast ? 0 : nl, 1, 1, 0, nl, 1};
         for (int s = 0; s < ORB_NSTAGES; s++) {
             e->stage_ms[s] = 0.f;
             e->stage_launches[s] = per_chunk[s] * e->prof_chunks;

@@ -84,7 +84,8 @@ __global__ __launch_bounds__(FC_THREADS) void k_fast_cell(const uint8_t* __restr
     extern __shared__ uint4 lds4[];
     __shared__ int cn;
     __shared__ int red[FC_WAVES];
-    const int c = blockIdx.x, f = blockIdx.y;
+    int c = blockIdx.x, f = blockIdx.y;
+    xcd_frame_swizzle(c, f, (int)gridDim.x, (int)gridDim.y);
     const CellDesc cd = cells[c];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int* out_total = n_total + (long long)f * g->cells_per_frame + c;

@@ -55,4 +55,27 @@ struct CellDesc {
     int pad_;
 };
 
+#ifdef __HIPCC__
+// Workgroups are handed to the eight XCDs (each with its own L2) round-robin by linear workgroup
+// id.  These helpers permute (inner index, frame) inside each group of eight frames so that XCD k
+// runs every workgroup of frame k of the group: workgroups that touch the same image rows then
+// share one L2.  `inner` counts the workgroups of one frame; frames past the last full group of
+// eight keep the identity mapping.  The permutation is a bijection of the launched grid.
+__device__ __forceinline__ void xcd_frame_swizzle(int& inner, int& frame, int inner_count, int frames) {
+    if (frame < (frames & ~7)) {
+        const uint32_t lin = (uint32_t)(frame & 7) * (uint32_t)inner_count + (uint32_t)inner;
+        frame = (frame & ~7) + (int)(lin & 7u);
+        inner = (int)(lin >> 3);
+    }
+}
+// 3-D grids (x, y, frame): returns the permuted (bx, by, f).
+__device__ __forceinline__ void xcd_frame_swizzle3(int& bx, int& by, int& frame) {
+    int inner = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    frame = (int)blockIdx.z;
+    xcd_frame_swizzle(inner, frame, (int)(gridDim.x * gridDim.y), (int)gridDim.z);
+    by = inner / (int)gridDim.x;
+    bx = inner - by * (int)gridDim.x;
+}
+#endif
+
 #endif
