@@ -182,8 +182,8 @@ def main():
         path_bytes = (5 * P + 60 * N_frame) * args.batch
         path_ms = sum(stage_ms.values())
         kernel_names = {"level0": "k_level0", "resize": "k_resize", "fast_measure": "k_score",
-                        "nms_compact": "k_fast_cell" if fused else "k_nms", "select": "k_select", "orient": "k_orient",
-                        "blur": "k_blur", "describe": "k_describe"}
+                        "nms_compact": "k_fast_cell" if fused else "k_nms", "select": "k_cell_select", "orient": "k_orient_describe",
+                        "blur": "k_blur", "describe": "k_orient_describe"}
         roofline = {"bound": "hbm", "kernel": kernel_names[dominant], "stage": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                     "launches_per_step": launches, "avg_launch_ms": round(avg_launch_ms, 5),

@@ -355,19 +355,22 @@ __global__ __launch_bounds__(256) void k_nms(const uint8_t* __restrict__ score, 
 
 // ---------------------------------------------------------------------------------------------
 // Quota redistribution (src/ORBextractor.cc:622-670), per-cell retainBest (:683-685), cell-major
-// concatenation in level coordinates (:687-694) and per-level retainBest (:697-701).
-// One workgroup per (level, frame).
-//   phase 1  quota loop: every pass over the cells is order-independent (sums and per-cell
-//            decisions), so it runs data-parallel with block reductions; the while loop itself is
-//            the reference's.
-//   phase 2  per-cell selection: one wave per cell, list staged in LDS, exact std::nth_element
-//            element movement with wave-parallel partitions (wave_select.h).
-//   phase 3  exclusive scan of nToRetain -> offsets; gather of the retained prefixes.
-//   phase 4  per-level selection by one wave.
+// concatenation in level coordinates (:687-694) and per-level retainBest (:697-701), as three
+// kernels so that the per-cell selections (the bulk of the work, one wave each) spread over the
+// whole chip instead of queueing behind the four waves of their level's workgroup:
+//   k_quota         one workgroup per (level, frame).  Every pass of the quota loop over the cells
+//                   is order-independent (sums and per-cell decisions), so it runs data-parallel
+//                   with block reductions; the while loop itself is the reference's.
+//   k_cell_select   one wave per (cell, frame): list staged in LDS, exact std::nth_element element
+//                   movement with wave-parallel partitions (wave_select.h); the permuted list goes
+//                   back to the cell's arena.
+//   k_level_select  one workgroup per (level, frame): exclusive scan of nToRetain -> offsets,
+//                   gather of the retained prefixes in level coordinates, per-level selection by
+//                   one wave, level list and count out.
 // Lists larger than the LDS staging areas are selected in place in global memory by one lane
 // (introselect.h) — same results, only slower.
-#define SEL_WCAP 1536
-#define SEL_LCAP (4 * SEL_WCAP)
+#define SEL_WCAP 1024
+#define SEL_LCAP 4096
 
 __device__ __forceinline__ int block_sum(int v, int* red, int tid) {
 #pragma unroll
@@ -378,10 +381,94 @@ __device__ __forceinline__ int block_sum(int v, int* red, int tid) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ __launch_bounds__(256) void k_select(const GeomDev* __restrict__ g, const CellDesc* __restrict__ cells,
-                                                uint32_t* __restrict__ cand, const int* __restrict__ n_total,
-                                                int* __restrict__ n_retain, uint32_t* __restrict__ lvl_list,
-                                                int* __restrict__ lvl_count, int* __restrict__ err) {
+__global__ __launch_bounds__(256) void k_quota(const GeomDev* __restrict__ g, const CellDesc* __restrict__ cells,
+                                               const int* __restrict__ n_total, int* __restrict__ n_retain) {
+    __shared__ int ltot[ORB_MAX_CELLS_PER_LEVEL];
+    __shared__ int lret[ORB_MAX_CELLS_PER_LEVEL];
+    __shared__ uint8_t done[ORB_MAX_CELLS_PER_LEVEL];
+    __shared__ int red[4];
+    const int level = blockIdx.x, f = blockIdx.y;
+    const LevelGeom& L = g->lv[level];
+    const int tid = threadIdx.x;
+    const int nCells = L.nCells;
+    const CellDesc* lc = cells + L.cell_base;
+    const int* tot = n_total + (long long)f * g->cells_per_frame + L.cell_base;
+    int* ret = n_retain + (long long)f * g->cells_per_frame + L.cell_base;
+    const int nfc = L.nfeaturesCell;
+    int d = 0, closed = 0;
+    for (int c = tid; c < nCells; c += 256) {
+        const bool skipped = lc[c].cw <= 0 || lc[c].ch <= 0;
+        const int nKeys = tot[c];
+        ltot[c] = nKeys;
+        if (skipped) {
+            lret[c] = 0;
+            done[c] = 0;
+        } else if (nKeys > nfc) {
+            lret[c] = nfc;
+            done[c] = 0;
+        } else {
+            lret[c] = nKeys;
+            d += nfc - nKeys;
+            done[c] = 1;
+            closed++;
+        }
+    }
+    int nToDistribute = block_sum(d, red, tid);
+    int nNoMore = block_sum(closed, red, tid);
+    while (nToDistribute > 0 && nNoMore < nCells) {
+        const int nNew = nfc + (int)ceilf((float)nToDistribute / (float)(nCells - nNoMore));
+        d = 0;
+        closed = 0;
+        for (int c = tid; c < nCells; c += 256)
+            if (!done[c]) {
+                const int nt = ltot[c];
+                if (nt > nNew) {
+                    lret[c] = nNew;
+                } else {
+                    lret[c] = nt;
+                    d += nNew - nt;
+                    done[c] = 1;
+                    closed++;
+                }
+            }
+        nToDistribute = block_sum(d, red, tid);
+        nNoMore += block_sum(closed, red, tid);
+    }
+    __syncthreads();
+    for (int c = tid; c < nCells; c += 256) ret[c] = lret[c];
+}
+
+__global__ __launch_bounds__(256) void k_cell_select(const GeomDev* __restrict__ g, const CellDesc* __restrict__ cells,
+                                                     uint32_t* __restrict__ cand, const int* __restrict__ n_total,
+                                                     const int* __restrict__ n_retain) {
+    __shared__ uint32_t buf[4 * SEL_WCAP];
+    __shared__ uint16_t lists[4 * 2 * SEL_WCAP];
+    int bx = blockIdx.x, f = blockIdx.y;
+    xcd_frame_swizzle(bx, f, (int)gridDim.x, (int)gridDim.y);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = bx * 4 + wave;
+    if (c >= g->cells_per_frame) return;
+    const long long fc = (long long)f * g->cells_per_frame + c;
+    const int n = n_total[fc], kk = n_retain[fc];
+    if (!(n > kk && kk > 0)) return;
+    uint32_t* list = cand + (long long)f * g->cand_per_frame + cells[c].cand_off;
+    if (n <= SEL_WCAP) {
+        uint32_t* wbuf = buf + wave * SEL_WCAP;
+        uint16_t* wl = lists + wave * 2 * SEL_WCAP;
+        for (int i = lane; i < n; i += 64) wbuf[i] = list[i];
+        orbsel::wave_lds_fence();
+        orbsel::wave_nth_element_desc(wbuf, n, kk, wl, wl + SEL_WCAP, lane);
+        // the whole permuted list goes back, so the cell list stays a permutation of the candidates
+        for (int i = lane; i < n; i += 64) list[i] = wbuf[i];
+    } else if (lane == 0) {
+        orbsel::nth_element_desc(list, n, kk);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_level_select(const GeomDev* __restrict__ g, const CellDesc* __restrict__ cells,
+                                                      const uint32_t* __restrict__ cand, const int* __restrict__ n_retain,
+                                                      uint32_t* __restrict__ lvl_list, int* __restrict__ lvl_count,
+                                                      int* __restrict__ err) {
     __shared__ uint32_t buf[SEL_LCAP];
     __shared__ uint16_t lists[2 * SEL_LCAP];
     __shared__ int aux[ORB_MAX_CELLS_PER_LEVEL + 1];
@@ -391,93 +478,15 @@ __global__ __launch_bounds__(256) void k_select(const GeomDev* __restrict__ g, c
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nCells = L.nCells;
     const CellDesc* lc = cells + L.cell_base;
-    const int* tot = n_total + (long long)f * g->cells_per_frame + L.cell_base;
-    int* ret = n_retain + (long long)f * g->cells_per_frame + L.cell_base;
-    uint32_t* fcand = cand + (long long)f * g->cand_per_frame;
+    const int* ret = n_retain + (long long)f * g->cells_per_frame + L.cell_base;
+    const uint32_t* fcand = cand + (long long)f * g->cand_per_frame;
 
-    // ---- phase 1 ------------------------------------------------------------------------------
-    int* ltot = (int*)lists;               // nCells ints
-    int* lret = ltot + ORB_MAX_CELLS_PER_LEVEL;  // nCells ints (lists holds 2*SEL_LCAP*2 bytes >= 2*2048*4)
-    const int nfc = L.nfeaturesCell;
-    {
-        int d = 0, closed = 0;
-        for (int c = tid; c < nCells; c += 256) {
-            const bool skipped = lc[c].cw <= 0 || lc[c].ch <= 0;
-            const int nKeys = tot[c];
-            ltot[c] = nKeys;
-            if (skipped) {
-                lret[c] = 0;
-                aux[c] = 0;
-            } else if (nKeys > nfc) {
-                lret[c] = nfc;
-                aux[c] = 0;
-            } else {
-                lret[c] = nKeys;
-                d += nfc - nKeys;
-                aux[c] = 1;
-                closed++;
-            }
-        }
-        int nToDistribute = block_sum(d, red, tid);
-        int nNoMore = block_sum(closed, red, tid);
-        while (nToDistribute > 0 && nNoMore < nCells) {
-            const int nNew = nfc + (int)ceilf((float)nToDistribute / (float)(nCells - nNoMore));
-            d = 0;
-            closed = 0;
-            for (int c = tid; c < nCells; c += 256)
-                if (!aux[c]) {
-                    const int nt = ltot[c];
-                    if (nt > nNew) {
-                        lret[c] = nNew;
-                    } else {
-                        lret[c] = nt;
-                        d += nNew - nt;
-                        aux[c] = 1;
-                        closed++;
-                    }
-                }
-            nToDistribute = block_sum(d, red, tid);
-            nNoMore += block_sum(closed, red, tid);
-        }
-        __syncthreads();
-        for (int c = tid; c < nCells; c += 256) {
-            const int r = lret[c];
-            aux[c] = r;
-            ret[c] = r;
-        }
-        __syncthreads();
-    }
-
-    // ---- phase 2: waves are independent, no block barrier inside --------------------------------
-    {
-        uint32_t* wbuf = buf + wave * SEL_WCAP;
-        uint16_t* wl = lists + wave * 2 * SEL_WCAP;
-        uint16_t* wr = wl + SEL_WCAP;
-        for (int c = wave; c < nCells; c += 4) {
-            const int n = tot[c], kk = aux[c];
-            if (!(n > kk && kk > 0)) continue;
-            uint32_t* list = fcand + lc[c].cand_off;
-            if (n <= SEL_WCAP) {
-                for (int i = lane; i < n; i += 64) wbuf[i] = list[i];
-                orbsel::wave_lds_fence();
-                orbsel::wave_nth_element_desc(wbuf, n, kk, wl, wr, lane);
-                // the whole permuted list goes back, so the cell list stays a permutation
-                for (int i = lane; i < n; i += 64) list[i] = wbuf[i];
-                orbsel::wave_lds_fence();
-            } else if (lane == 0) {
-                orbsel::nth_element_desc(list, n, kk);
-            }
-        }
-    }
-    __threadfence_block();
-    __syncthreads();
-
-    // ---- phase 3: exclusive scan of nToRetain over the cells (8 consecutive cells per thread) ----
+    // ---- exclusive scan of nToRetain over the cells (consecutive cells per thread) ----------------
     {
         const int per = (nCells + 255) / 256;
         const int c0 = min(tid * per, nCells), c1 = min(c0 + per, nCells);
         int s = 0;
-        for (int c = c0; c < c1; c++) s += aux[c];
+        for (int c = c0; c < c1; c++) s += ret[c];
         int incl = s;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -491,9 +500,8 @@ __global__ __launch_bounds__(256) void k_select(const GeomDev* __restrict__ g, c
         const int grand = red[0] + red[1] + red[2] + red[3];
         int run = woff + incl - s;
         for (int c = c0; c < c1; c++) {
-            const int r = aux[c];
             aux[c] = run;
-            run += r;
+            run += ret[c];
         }
         if (tid == 0) aux[nCells] = grand;
         __syncthreads();
@@ -516,7 +524,7 @@ __global__ __launch_bounds__(256) void k_select(const GeomDev* __restrict__ g, c
     __threadfence_block();
     __syncthreads();
 
-    // ---- phase 4 ------------------------------------------------------------------------------
+    // ---- per-level selection ------------------------------------------------------------------------
     const int quota = L.quota;
     if (total > quota) {
         if (lstaged) {
@@ -870,8 +878,10 @@ void launch_nms(hipStream_t st, const GeomDev& hg, int batch, int max_cell_h, co
 
 void launch_select(hipStream_t st, const GeomDev& hg, int batch, const GeomDev* dg, const CellDesc* cells,
                    uint32_t* cand, const int* n_total, int* n_retain, uint32_t* lvl_list, int* lvl_count, int* err) {
-    dim3 grid(hg.nlevels, batch), block(256);
-    hipLaunchKernelGGL(k_select, grid, block, 0, st, dg, cells, cand, n_total, n_retain, lvl_list, lvl_count, err);
+    dim3 per_level(hg.nlevels, batch), per_cell((hg.cells_per_frame + 3) / 4, batch), block(256);
+    hipLaunchKernelGGL(k_quota, per_level, block, 0, st, dg, cells, n_total, n_retain);
+    hipLaunchKernelGGL(k_cell_select, per_cell, block, 0, st, dg, cells, cand, n_total, n_retain);
+    hipLaunchKernelGGL(k_level_select, per_level, block, 0, st, dg, cells, cand, n_retain, lvl_list, lvl_count, err);
 }
 
 void launch_blur(hipStream_t st, const GeomDev& hg, int batch, int level, const uint8_t* pyr, uint8_t* blur,

@@ -567,7 +567,7 @@ int orbhip_extractor_synchronize(orbhip_extractor* e) {
     }
     if (e->profiling) {
         const int nl = e->nlevels;
-        const int per_chunk[ORB_NSTAGES] = {1, nl - 1, e->fused_fast ? 0 : nl, 1, 1, 0, nl, 1};
+        const int per_chunk[ORB_NSTAGES] = {1, nl - 1, e->fused_fast ? 0 : nl, 1, 3, 0, nl, 1};
         for (int s = 0; s < ORB_NSTAGES; s++) {
             e->stage_ms[s] = 0.f;
             e->stage_launches[s] = per_chunk[s] * e->prof_chunks;

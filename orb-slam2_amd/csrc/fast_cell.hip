@@ -105,6 +105,7 @@ __global__ __launch_bounds__(FC_THREADS) void k_fast_cell(const uint8_t* __restr
     const int spitch = (cw + 2 + 3) & ~3;
     const int bw = (cw + 31) >> 5;  // bitmap words per row
     const int nwords = bw * ch;
+    const uint32_t bw_inv = (65536u + (uint32_t)bw - 1u) / (uint32_t)bw;
     const int gy0 = ORB_EDGE + cd.y0 - 3;
     uint8_t* imgb = (uint8_t*)lds4;
     uint8_t* scb = imgb + pitch * th;  // (ch + 2) rows of spitch bytes, zero border
@@ -113,17 +114,26 @@ __global__ __launch_bounds__(FC_THREADS) void k_fast_cell(const uint8_t* __restr
     uint16_t* clist = qlist + FC_QCAP;
 
     {
+        // 16 lanes per tile row (pitch <= 256 bytes = 16 chunks), 32 rows per sweep of the block and
+        // up to four rows in flight per lane; no index division
         const int pc = pitch >> 4;
-        const int nchunk = pc * th;
-        uint4* dst = (uint4*)imgb;
-        for (int i0 = 0; i0 < nchunk; i0 += 2 * FC_THREADS) {
-            // two 16-byte loads in flight per lane before the LDS stores
-            const int ia = min(i0 + tid, nchunk - 1), ib = min(i0 + FC_THREADS + tid, nchunk - 1);
-            const int ra = ia / pc, rb2 = ib / pc;
-            const uint4 va = *(const uint4*)(plane + (long long)(gy0 + ra) * stride + gxs + 16 * (ia - ra * pc));
-            const uint4 vb = *(const uint4*)(plane + (long long)(gy0 + rb2) * stride + gxs + 16 * (ib - rb2 * pc));
-            dst[ia] = va;
-            dst[ib] = vb;
+        const int cj = tid & 15, r0 = tid >> 4;
+        if (cj < pc) {
+            const uint8_t* src = plane + (long long)gy0 * stride + gxs + 16 * cj;
+            uint4* dst = (uint4*)imgb + cj;
+            for (int r = r0; r < th; r += 128) {
+                // rows past the end are clamped to the last row (same bytes stored twice), so that
+                // the four loads are unconditional and issue back to back
+                uint4 v[4];
+                int rr[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    rr[k] = min(r + 32 * k, th - 1);
+                    v[k] = *(const uint4*)(src + (long long)rr[k] * stride);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) dst[rr[k] * pc] = v[k];
+            }
         }
     }
 
@@ -264,7 +274,8 @@ __global__ __launch_bounds__(FC_THREADS) void k_fast_cell(const uint8_t* __restr
     }
     for (int w = w0; w < w1; w++) {
         uint32_t bits = bm[w];
-        const int r = w / bw, xb = (w - r * bw) << 5;
+        // w / bw by multiplication: bw <= 8 and w < 2048, so the rounding error stays below 1 / bw
+        const int r = (int)(((uint32_t)w * bw_inv) >> 16), xb = (w - r * bw) << 5;
         while (bits) {
             const int b = __ffs(bits) - 1;
             bits &= bits - 1;
