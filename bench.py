@@ -86,6 +86,25 @@ def cpu_baseline(frames, nfeatures, threads, sample):
     return sample / dt, results
 
 
+
+def _pmc_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/*pmc_traffic.json,
+    made by tools/pmc_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+    same workload).  Counters cannot be collected from inside the timed run, so the figure is the one
+    of the latest committed pass; None if there is none or the workload is not the default one."""
+    if (args.batch, args.width, args.height, args.features) != (256, 1280, 720, 2000):
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))["kernels"].get(kernel)
+        return k["traffic"] if k else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,7 +204,8 @@ def main():
                         "nms_compact": "k_fast_cell" if fused else "k_nms", "select": "k_cell_select", "orient": "k_orient_describe",
                         "blur": "k_blur", "describe": "k_orient_describe"}
         roofline = {"bound": "hbm", "kernel": kernel_names[dominant], "stage": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                    "traffic": _pmc_traffic(kernel_names[dominant], args),
                     "launches_per_step": launches, "avg_launch_ms": round(avg_launch_ms, 5),
                     "algorithmic_bytes_per_launch": int(bytes_per_launch),
                     "stage_ms_per_step": {s: round(v, 4) for s, v in stage_ms.items()},

@@ -424,7 +424,7 @@ int orbhip_extractor_create(orbhip_extractor** out, int nfeatures, float scale_f
         }
         {
             const char* env = getenv("ORBHIP_STREAMS");
-            int nw = env ? atoi(env) : 4;
+            int nw = env ? atoi(env) : 2;
             nw = std::max(1, std::min(nw, 16));
             bool ok = true;
             for (int i = 0; i < nw && ok; i++) {
