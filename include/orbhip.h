@@ -155,6 +155,72 @@ float orbhip_matcher_last_elapsed_ms(orbhip_matcher* m);
  * 2 = v_add_u32.  Returns 0 on failure. */
 double orbhip_valu_rate(orbhip_matcher* m, int mode);
 
+/* ---- Feature grid of a frame and the windowed matchers that take their candidates from it -------
+ * Batched over independent frames / frame pairs; every pointer is a device pointer and the calls
+ * are asynchronous on the matcher's stream unless stated otherwise.  Frame f has d_n[f] keypoints
+ * at d_kp + f*cap (records as written by orbhip_extract_batch_device) and descriptors at
+ * d_desc + f*cap*32.  cap <= ORBHIP_FRAME_MAX_KEYPOINTS. */
+#define ORBHIP_FRAME_GRID_COLS 64 /* include/Frame.h:38 */
+#define ORBHIP_FRAME_GRID_ROWS 48 /* include/Frame.h:37 */
+#define ORBHIP_FRAME_GRID_CELLS (ORBHIP_FRAME_GRID_COLS * ORBHIP_FRAME_GRID_ROWS)
+#define ORBHIP_FRAME_MAX_KEYPOINTS 8192
+/* Frame::mnMinX, mnMinY, mnMaxX, mnMaxY (src/Frame.cc:322-350): {0, 0, cols, rows} for an
+ * undistorted camera. */
+typedef struct OrbFrameBounds {
+    int32_t min_x, min_y, max_x, max_y;
+} OrbFrameBounds;
+
+/* Replaces the grid assignment of the Frame constructor (src/Frame.cc:78-79,110-124) and
+ * Frame::PosInGrid (:268-278).  mGrid[ix][iy] of frame f is
+ * d_cell_items[f*cap + d_cell_start[f*(CELLS+1) + c] ... d_cell_start[f*(CELLS+1) + c + 1]) with
+ * c = ix*ORBHIP_FRAME_GRID_ROWS + iy, in push_back (ascending keypoint index) order; keypoints that
+ * PosInGrid rejects are in no cell. */
+int orbhip_frame_grid_device(orbhip_matcher* m, const OrbKeypoint* d_kp, const int32_t* d_n, int batch, int cap,
+                             OrbFrameBounds bounds, int32_t* d_cell_start, int32_t* d_cell_items);
+
+/* One call of Frame::GetFeaturesInArea(x, y, r, minLevel, maxLevel); minLevel = maxLevel = -1
+ * switches the level check off. */
+typedef struct OrbAreaQuery {
+    float x, y, r;
+    int32_t min_level, max_level;
+} OrbAreaQuery;
+/* Replaces Frame::GetFeaturesInArea (src/Frame.cc:201-266), nq queries per frame
+ * (d_queries[f*nq + q]).  The indices query q returns, in the reference's order (grid column
+ * outer, grid row inner, push order inside a cell), are
+ * d_out[f*out_cap + d_out_start[f*(nq+1) + q] ... d_out_start[f*(nq+1) + q + 1]).  A frame whose
+ * queries return more than out_cap indices in total makes the next orbhip_matcher_synchronize
+ * fail with ORBHIP_ECAP (the starts are still complete, so the caller can size a retry). */
+int orbhip_features_in_area_device(orbhip_matcher* m, const OrbKeypoint* d_kp, const int32_t* d_n, int batch, int cap,
+                                   OrbFrameBounds bounds, const int32_t* d_cell_start, const int32_t* d_cell_items,
+                                   const OrbAreaQuery* d_queries, int nq, int32_t* d_out_start, int32_t* d_out,
+                                   int out_cap);
+
+/* Replaces ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:609-724) for `batch` independent
+ * frame pairs (F1 = *_1, F2 = *_2 with its grid).  d_prev_matched (batch*cap*2 floats, x then y) is
+ * vbPrevMatched: read as the window centres and updated for the matched keypoints.  Outputs
+ * d_matches12 (batch*cap, vnMatches12: index in F2 or -1) and d_nmatches (batch).  The sequential
+ * dependence of the reference (a later keypoint of F1 can take a feature of F2 away from an
+ * earlier one, rotation histogram over every accepted match) is reproduced exactly.
+ * Blocking: sizes an internal workspace from a device count. */
+int orbhip_search_for_initialization_device(orbhip_matcher* m, const OrbKeypoint* d_kp1, const uint8_t* d_desc1,
+                                            const int32_t* d_n1, const OrbKeypoint* d_kp2, const uint8_t* d_desc2,
+                                            const int32_t* d_n2, const int32_t* d_cell_start2,
+                                            const int32_t* d_cell_items2, int batch, int cap, OrbFrameBounds bounds,
+                                            float* d_prev_matched, int window_size, float nnratio,
+                                            int check_orientation, int32_t* d_matches12, int32_t* d_nmatches);
+
+/* Replaces ORBmatcher::WindowSearch (src/ORBmatcher.cc:420-527).  d_valid1[f*cap + i] != 0 stands
+ * for "F1.mvpMapPoints[i] exists and is not bad"; min_level <= 0 and max_level == INT_MAX switch
+ * the level filters off as in the reference.  Output d_matches21 (batch*cap): the F1 index whose
+ * map point is assigned to each F2 feature (vpMapPointMatches2[i2] = F1.mvpMapPoints[that]) or -1;
+ * d_nmatches (batch).  Blocking, as above. */
+int orbhip_window_search_device(orbhip_matcher* m, const OrbKeypoint* d_kp1, const uint8_t* d_desc1,
+                                const int32_t* d_n1, const uint8_t* d_valid1, const OrbKeypoint* d_kp2,
+                                const uint8_t* d_desc2, const int32_t* d_n2, const int32_t* d_cell_start2,
+                                const int32_t* d_cell_items2, int batch, int cap, OrbFrameBounds bounds,
+                                int window_size, int min_level, int max_level, float nnratio, int check_orientation,
+                                int32_t* d_matches21, int32_t* d_nmatches);
+
 /* Device self-tests of the arithmetic helpers (test instrumentation, host pointers, blocking):
  * which 0: n (y, x) float pairs -> n floats, the device's fastAtan2 in degrees
  *       1: n float angles (radians) -> n (cos, sin) float pairs as the descriptor kernel computes them

@@ -100,6 +100,25 @@ void orbref_three_maxima(const int32_t* sizes, int L, int32_t* ind3);
 /* Rotation-histogram bin of a match (src/ORBmatcher.cc:493-498). */
 int orbref_rot_bin(float angle1, float angle2);
 
+/* ---- Frame feature grid and the windowed matchers built on it (oracle/frame_ref.cpp) ----------
+ * kp: 28-byte keypoint records {x,y,size,angle,response,octave,class_id}; bounds = {mnMinX, mnMinY,
+ * mnMaxX, mnMaxY} (src/Frame.cc:322-350; {0,0,cols,rows} without distortion). */
+/* Frame grid (src/Frame.cc:110-124,268-278) as CSR: cell = ix*48 + iy, 64*48+1 starts, n items max. */
+void orbref_frame_grid(const void* kp, int n, const int32_t bounds[4], int32_t* cell_start, int32_t* items);
+/* Frame::GetFeaturesInArea (src/Frame.cc:201-266); returns the count, writes at most cap indices. */
+int orbref_features_in_area(const void* kp, int n, const int32_t bounds[4], float x, float y, float r, int min_level,
+                            int max_level, int32_t* out, int cap);
+/* ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:609-724); prev_matched_xy (2*n1 floats) is
+ * read and updated like vbPrevMatched; returns nmatches, fills vnMatches12[n1]. */
+int orbref_search_for_initialization(const void* kp1, const uint8_t* desc1, int n1, const void* kp2, const uint8_t* desc2,
+                                     int n2, const int32_t bounds[4], float* prev_matched_xy, int window_size,
+                                     float nnratio, int check_orientation, int32_t* matches12);
+/* ORBmatcher::WindowSearch (src/ORBmatcher.cc:420-527); valid1[i] != 0 <=> F1.mvpMapPoints[i] is a good
+ * map point; fills matches21[n2] with the F1 index assigned to each F2 feature (-1 = none). */
+int orbref_window_search(const void* kp1, const uint8_t* desc1, int n1, const uint8_t* valid1, const void* kp2,
+                         const uint8_t* desc2, int n2, const int32_t bounds[4], int window_size, int min_level,
+                         int max_level, float nnratio, int check_orientation, int32_t* matches21);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,7 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("orb_ref.cpp", "orb_ref.h")]
+    src = [os.path.join(_HERE, f) for f in ("orb_ref.cpp", "frame_ref.cpp", "orb_ref.h")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
         subprocess.check_call(["make", "-C", _HERE, "liborbref.so"])
     return _SO
@@ -70,6 +70,11 @@ def lib():
         L.orbref_ratio_accept.argtypes = [i32, i32, f32, i32]
         L.orbref_three_maxima.argtypes = [vp, i32, vp]
         L.orbref_rot_bin.argtypes = [f32, f32]
+        L.orbref_frame_grid.restype = None
+        L.orbref_frame_grid.argtypes = [vp, i32, vp, vp, vp]
+        L.orbref_features_in_area.argtypes = [vp, i32, vp, f32, f32, f32, i32, i32, vp, i32]
+        L.orbref_search_for_initialization.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, i32, f32, i32, vp]
+        L.orbref_window_search.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, f32, i32, vp]
         _lib = L
     return _lib
 
@@ -172,3 +177,60 @@ def knn2(q, t):
     d2 = np.zeros(nq, np.int32)
     lib().orbref_knn2(_p(q), nq, _p(t), nt, _p(idx), _p(d1), _p(d2))
     return idx, d1, d2
+
+
+# ---- Frame feature grid and windowed matchers (oracle/frame_ref.cpp) ----------------------------
+FRAME_GRID_COLS, FRAME_GRID_ROWS = 64, 48
+INT_MAX = 2**31 - 1
+
+
+def _bounds(b):
+    return np.ascontiguousarray(b, dtype=np.int32).reshape(4)
+
+
+def frame_grid(kp, bounds):
+    """CSR form of Frame::mGrid: (cell_start[64*48+1], items[...]) with cell = ix*48 + iy."""
+    kp = np.ascontiguousarray(kp, dtype=KP_DTYPE)
+    b = _bounds(bounds)
+    start = np.zeros(FRAME_GRID_COLS * FRAME_GRID_ROWS + 1, np.int32)
+    items = np.zeros(max(len(kp), 1), np.int32)
+    lib().orbref_frame_grid(_p(kp), len(kp), _p(b), _p(start), _p(items))
+    return start, items[:start[-1]].copy()
+
+
+def features_in_area(kp, bounds, x, y, r, min_level=-1, max_level=-1):
+    kp = np.ascontiguousarray(kp, dtype=KP_DTYPE)
+    b = _bounds(bounds)
+    out = np.zeros(max(len(kp), 1), np.int32)
+    n = lib().orbref_features_in_area(_p(kp), len(kp), _p(b), x, y, r, min_level, max_level, _p(out), len(out))
+    return out[:n].copy()
+
+
+def search_for_initialization(kp1, desc1, kp2, desc2, bounds, prev_matched, window_size=100, nnratio=0.9,
+                              check_orientation=True):
+    """Returns (nmatches, vnMatches12, updated vbPrevMatched)."""
+    kp1 = np.ascontiguousarray(kp1, dtype=KP_DTYPE)
+    kp2 = np.ascontiguousarray(kp2, dtype=KP_DTYPE)
+    desc1 = np.ascontiguousarray(desc1, dtype=np.uint8).reshape(-1, 32)
+    desc2 = np.ascontiguousarray(desc2, dtype=np.uint8).reshape(-1, 32)
+    b = _bounds(bounds)
+    prev = np.array(prev_matched, dtype=np.float32).reshape(-1, 2).copy()
+    m12 = np.zeros(max(len(kp1), 1), np.int32)
+    n = lib().orbref_search_for_initialization(_p(kp1), _p(desc1), len(kp1), _p(kp2), _p(desc2), len(kp2), _p(b),
+                                               _p(prev), window_size, nnratio, int(check_orientation), _p(m12))
+    return n, m12[:len(kp1)].copy(), prev
+
+
+def window_search(kp1, desc1, valid1, kp2, desc2, bounds, window_size, min_level=-1, max_level=INT_MAX, nnratio=0.6,
+                  check_orientation=True):
+    """Returns (nmatches, vnMatches21)."""
+    kp1 = np.ascontiguousarray(kp1, dtype=KP_DTYPE)
+    kp2 = np.ascontiguousarray(kp2, dtype=KP_DTYPE)
+    desc1 = np.ascontiguousarray(desc1, dtype=np.uint8).reshape(-1, 32)
+    desc2 = np.ascontiguousarray(desc2, dtype=np.uint8).reshape(-1, 32)
+    valid1 = np.ascontiguousarray(valid1, dtype=np.uint8)
+    b = _bounds(bounds)
+    m21 = np.zeros(max(len(kp2), 1), np.int32)
+    n = lib().orbref_window_search(_p(kp1), _p(desc1), len(kp1), _p(valid1), _p(kp2), _p(desc2), len(kp2), _p(b),
+                                   window_size, min_level, max_level, nnratio, int(check_orientation), _p(m21))
+    return n, m21[:len(kp2)].copy()

@@ -39,6 +39,11 @@ def _preload_torch_hip_runtime():
             pass
 
 
+class OrbFrameBounds(C.Structure):
+    """Frame::mnMinX, mnMinY, mnMaxX, mnMaxY (src/Frame.cc:322-350)."""
+    _fields_ = [("min_x", C.c_int32), ("min_y", C.c_int32), ("max_x", C.c_int32), ("max_y", C.c_int32)]
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -84,6 +89,12 @@ def lib():
     L.orbhip_extractor_set_profiling.argtypes = [vp, i32]
     L.orbhip_extractor_stage_times.argtypes = [vp, vp, vp]
     L.orbhip_selftest.argtypes = [i32, vp, i32, i32, vp]
+    L.orbhip_frame_grid_device.argtypes = [vp, vp, vp, i32, i32, OrbFrameBounds, vp, vp]
+    L.orbhip_features_in_area_device.argtypes = [vp, vp, vp, i32, i32, OrbFrameBounds, vp, vp, vp, i32, vp, vp, i32]
+    L.orbhip_search_for_initialization_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, OrbFrameBounds,
+                                                          vp, i32, f32, i32, vp, vp]
+    L.orbhip_window_search_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, OrbFrameBounds,
+                                              i32, i32, i32, f32, i32, vp, vp]
     L.orbhip_device_count.argtypes = []
     L.orbhip_version.restype = C.c_char_p
     L.orbhip_last_error.restype = C.c_char_p

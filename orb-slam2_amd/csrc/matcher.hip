@@ -18,6 +18,7 @@
 
 #include "../../include/orbhip.h"
 #include "common.h"
+#include "matcher_internal.h"
 
 namespace {
 
@@ -199,26 +200,7 @@ __global__ __launch_bounds__(256) void k_valu_rate(uint32_t* out, int iters, int
     out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
 }
 
-#define HIPCHK(call)                                                                         \
-    do {                                                                                     \
-        hipError_t err__ = (call);                                                           \
-        if (err__ != hipSuccess)                                                             \
-            return orb_fail(ORBHIP_EHIP, "%s failed: %s", #call, hipGetErrorString(err__)); \
-    } while (0)
-
 }  // namespace
-
-struct orbhip_matcher {
-    int device;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    float last_ms = 0.f;
-    void* d_part = nullptr;
-    size_t part_bytes = 0;
-    void* d_stage = nullptr;  // staging of the host-pointer entry point
-    size_t stage_bytes = 0;
-    int sm_count = 256;
-};
 
 extern "C" {
 
@@ -240,7 +222,8 @@ int orbhip_matcher_create(orbhip_matcher** out, int device) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) m->sm_count = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&m->ev0) != hipSuccess ||
-        hipEventCreate(&m->ev1) != hipSuccess) {
+        hipEventCreate(&m->ev1) != hipSuccess || hipMalloc((void**)&m->d_err, sizeof(int)) != hipSuccess ||
+        hipMemset(m->d_err, 0, sizeof(int)) != hipSuccess) {
         orbhip_matcher_destroy(m);
         return orb_fail(ORBHIP_EHIP, "stream/event creation failed");
     }
@@ -254,6 +237,8 @@ void orbhip_matcher_destroy(orbhip_matcher* m) {
     if (m->stream) hipStreamSynchronize(m->stream);
     if (m->d_part) hipFree(m->d_part);
     if (m->d_stage) hipFree(m->d_stage);
+    if (m->d_work) hipFree(m->d_work);
+    if (m->d_err) hipFree(m->d_err);
     if (m->ev0) hipEventDestroy(m->ev0);
     if (m->ev1) hipEventDestroy(m->ev1);
     if (m->stream) hipStreamDestroy(m->stream);
@@ -264,7 +249,16 @@ int orbhip_matcher_synchronize(orbhip_matcher* m) {
     if (!m) return orb_fail(ORBHIP_EINVAL, "null matcher");
     HIPCHK(hipSetDevice(m->device));
     HIPCHK(hipStreamSynchronize(m->stream));
-    if (hipEventElapsedTime(&m->last_ms, m->ev0, m->ev1) != hipSuccess) m->last_ms = 0.f;
+    if (hipEventElapsedTime(&m->last_ms, m->ev0, m->ev1) != hipSuccess) {
+        m->last_ms = 0.f;
+        (void)hipGetLastError();
+    }
+    int flags = 0;
+    HIPCHK(hipMemcpy(&flags, m->d_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (flags) {
+        hipMemset(m->d_err, 0, sizeof(int));
+        return orb_fail(ORBHIP_ECAP, "device output capacity exceeded (flags %d)", flags);
+    }
     return ORBHIP_OK;
 }
 
@@ -329,6 +323,8 @@ int orbhip_knn2(orbhip_matcher* m, const uint8_t* q, int nq, const uint8_t* t, i
     if (need > m->stage_bytes) {
         HIPCHK(hipStreamSynchronize(m->stream));
         if (m->d_stage) hipFree(m->d_stage);
+    if (m->d_work) hipFree(m->d_work);
+    if (m->d_err) hipFree(m->d_err);
         m->d_stage = nullptr;
         m->stage_bytes = 0;
         if (hipMalloc(&m->d_stage, need) != hipSuccess) return orb_fail(ORBHIP_ENOMEM, "hipMalloc of %zu bytes failed", need);

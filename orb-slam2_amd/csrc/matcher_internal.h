@@ -1,0 +1,32 @@
+// State of a matcher handle, shared by the translation units that implement its entry points.
+#ifndef ORBHIP_MATCHER_INTERNAL_H
+#define ORBHIP_MATCHER_INTERNAL_H
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+#include "../../include/orbhip.h"
+#include "common.h"
+
+#define HIPCHK(call)                                                                         \
+    do {                                                                                     \
+        hipError_t err__ = (call);                                                           \
+        if (err__ != hipSuccess)                                                             \
+            return orb_fail(ORBHIP_EHIP, "%s failed: %s", #call, hipGetErrorString(err__)); \
+    } while (0)
+
+struct orbhip_matcher {
+    int device;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_ms = 0.f;
+    void* d_part = nullptr;
+    size_t part_bytes = 0;
+    void* d_stage = nullptr;  // staging of the host-pointer entry point
+    size_t stage_bytes = 0;
+    void* d_work = nullptr;  // workspace of the windowed matchers
+    size_t work_bytes = 0;
+    int* d_err = nullptr;  // device error flags, read by orbhip_matcher_synchronize
+    int sm_count = 256;
+};
+
+#endif

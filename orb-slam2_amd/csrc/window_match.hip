@@ -1,0 +1,720 @@
+// Feature grid of a frame and the windowed matchers of the reference that draw their candidates
+// from it, for gfx950, batched over independent frames / frame pairs:
+//   Frame grid               src/Frame.cc:78-79,110-124,268-278 (include/Frame.h:37-38,90-92)
+//   Frame::GetFeaturesInArea src/Frame.cc:201-266
+//   ORBmatcher::WindowSearch src/ORBmatcher.cc:420-527
+//   ORBmatcher::SearchForInitialization  src/ORBmatcher.cc:609-724
+//
+// Both matchers are sequential in the reference: whether keypoint i1 of F1 may take feature i2 of
+// F2 depends on what earlier keypoints took.  The work splits into
+//   1. candidate generation + Hamming distances, independent per keypoint of F1 (one lane each):
+//      count pass, per-frame exclusive scan, fill pass -> CSR lists of (i2, distance) in the exact
+//      order GetFeaturesInArea returns them;
+//   2. resolution, one wave per frame pair, walking the keypoints of F1 in order with the
+//      reference's state (vMatchedDistance / vnMatches21 / vnMatches12) in LDS; the candidates of
+//      one keypoint are examined by the 64 lanes at once and reduced with the ordered-minimum rule
+//      (first candidate in list order attaining the minimum; second order statistic with
+//      multiplicity); the next keypoint's candidates are in flight while the current one is resolved;
+//   3. rotation histogram, ComputeThreeMaxima (src/ORBmatcher.cc:1759-1800) and the final filter.
+// All float expressions are evaluated operation by operation in fp32 (no contraction), as the
+// reference's are.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <vector>
+
+#include "matcher_internal.h"
+
+namespace {
+
+#define GRID_COLS ORBHIP_FRAME_GRID_COLS
+#define GRID_ROWS ORBHIP_FRAME_GRID_ROWS
+#define GRID_CELLS ORBHIP_FRAME_GRID_CELLS
+#define HISTO_LENGTH 30
+#define TH_HIGH 100
+#define TH_LOW 20
+#define NONE16 0xffffu
+#define KEY_NONE 0xffffffffffffffffull
+
+struct GridGeom {
+    float min_x, min_y;  // (float)mnMinX, (float)mnMinY
+    float inv_w, inv_h;  // mfGridElementWidthInv, mfGridElementHeightInv
+};
+
+struct KpDev {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+};
+
+// std::round(float): half away from zero
+__device__ __forceinline__ float round_half_away(float v) {
+    const float t = truncf(v);
+    const float fr = fabsf(__fsub_rn(v, t));
+    return fr >= 0.5f ? (v < 0.f ? t - 1.f : t + 1.f) : t;
+}
+
+// Frame::PosInGrid (src/Frame.cc:268-278); -1 if the keypoint is in no cell
+__device__ __forceinline__ int pos_in_grid(const GridGeom& gg, float x, float y) {
+    const int posX = (int)round_half_away(__fmul_rn(__fsub_rn(x, gg.min_x), gg.inv_w));
+    const int posY = (int)round_half_away(__fmul_rn(__fsub_rn(y, gg.min_y), gg.inv_h));
+    if (posX < 0 || posX >= GRID_COLS || posY < 0 || posY >= GRID_ROWS) return -1;
+    return posX * GRID_ROWS + posY;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Grid build: one workgroup per frame.  Keys (cell << 13 | keypoint index) are sorted in LDS
+// (bitonic network; keys are distinct, so the order is the reference's push_back order inside
+// every cell), then the cell starts are lower bounds in the sorted keys.
+#define GB_THREADS 256
+__global__ __launch_bounds__(GB_THREADS) void k_frame_grid(const KpDev* __restrict__ kp, const int32_t* __restrict__ n_arr,
+                                                           int cap, GridGeom gg, int32_t* __restrict__ cell_start,
+                                                           int32_t* __restrict__ cell_items) {
+    extern __shared__ uint32_t keys[];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int n = min(max(n_arr[f], 0), cap);
+    int np2 = 64;
+    while (np2 < n) np2 <<= 1;
+    const KpDev* fk = kp + (long long)f * cap;
+    for (int i = tid; i < np2; i += GB_THREADS) {
+        uint32_t key = 0xffffffffu;
+        if (i < n) {
+            const int c = pos_in_grid(gg, fk[i].x, fk[i].y);
+            if (c >= 0) key = ((uint32_t)c << 13) | (uint32_t)i;
+        }
+        keys[i] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (np2 >> 1); t += GB_THREADS) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // index with bit j clear
+                const int hi = lo | j;
+                const uint32_t a = keys[lo], b = keys[hi];
+                const bool up = (lo & k) == 0;
+                if ((a > b) == up) {
+                    keys[lo] = b;
+                    keys[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    int32_t* cs = cell_start + (long long)f * (GRID_CELLS + 1);
+    for (int c = tid; c <= GRID_CELLS; c += GB_THREADS) {
+        const uint32_t bound = (uint32_t)c << 13;  // first key of cell c; cell GRID_CELLS bounds the valid keys
+        int lo = 0, hi = np2;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (keys[mid] < bound) lo = mid + 1;
+            else hi = mid;
+        }
+        cs[c] = lo;
+    }
+    int32_t* it = cell_items + (long long)f * cap;
+    for (int i = tid; i < n; i += GB_THREADS) {
+        const uint32_t key = keys[i];
+        if (key != 0xffffffffu) it[i] = (int32_t)(key & 0x1fffu);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Candidate enumeration of one GetFeaturesInArea call.  Cells (ix, iyMin..iyMax) of one grid
+// column are consecutive in the CSR arrays, so a column is one contiguous run of items.
+struct AreaQuery {
+    float x, y, r;
+    int min_level, max_level;
+    bool active;
+};
+
+template <class Visit>
+__device__ __forceinline__ void for_each_in_area(const GridGeom& gg, const KpDev* __restrict__ kp,
+                                                 const int32_t* __restrict__ cs, const int32_t* __restrict__ items,
+                                                 const AreaQuery& q, Visit visit) {
+    const float fx = __fsub_rn(q.x, gg.min_x), fy = __fsub_rn(q.y, gg.min_y);
+    int nMinCellX = (int)floorf(__fmul_rn(__fsub_rn(fx, q.r), gg.inv_w));
+    nMinCellX = max(0, nMinCellX);
+    if (nMinCellX >= GRID_COLS) return;
+    int nMaxCellX = (int)ceilf(__fmul_rn(__fadd_rn(fx, q.r), gg.inv_w));
+    nMaxCellX = min(GRID_COLS - 1, nMaxCellX);
+    if (nMaxCellX < 0) return;
+    int nMinCellY = (int)floorf(__fmul_rn(__fsub_rn(fy, q.r), gg.inv_h));
+    nMinCellY = max(0, nMinCellY);
+    if (nMinCellY >= GRID_ROWS) return;
+    int nMaxCellY = (int)ceilf(__fmul_rn(__fadd_rn(fy, q.r), gg.inv_h));
+    nMaxCellY = min(GRID_ROWS - 1, nMaxCellY);
+    if (nMaxCellY < 0) return;
+    const bool bCheckLevels = !(q.min_level == -1 && q.max_level == -1);
+    const bool bSameLevel = bCheckLevels && q.min_level == q.max_level;
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+        if (nMinCellY > nMaxCellY) continue;
+        const int j0 = cs[ix * GRID_ROWS + nMinCellY], j1 = cs[ix * GRID_ROWS + nMaxCellY + 1];
+        for (int j = j0; j < j1; j++) {
+            const int i2 = items[j];
+            const KpDev& k = kp[i2];
+            if (bCheckLevels && !bSameLevel) {
+                if (k.octave < q.min_level || k.octave > q.max_level) continue;
+            } else if (bSameLevel) {
+                if (k.octave != q.min_level) continue;
+            }
+            if (fabsf(__fsub_rn(k.x, q.x)) > q.r || fabsf(__fsub_rn(k.y, q.y)) > q.r) continue;
+            visit(i2);
+        }
+    }
+}
+
+// How the queries of a frame are defined.
+enum { MODE_EXPLICIT = 0, MODE_SEARCH_INIT = 1, MODE_WINDOW = 2 };
+struct QuerySource {
+    int mode;
+    const OrbAreaQuery* queries;  // MODE_EXPLICIT: nq per frame
+    const KpDev* kp1;             // the matchers: keypoints of F1 (cap per frame)
+    const int32_t* n1;
+    const float* prev;            // MODE_SEARCH_INIT: vbPrevMatched (cap * 2 floats per frame)
+    const uint8_t* valid1;        // MODE_WINDOW
+    float r;
+    int min_level, max_level;     // MODE_WINDOW: minScaleLevel, maxScaleLevel
+    int nq;                       // queries per frame (= cap for the matchers)
+};
+
+__device__ __forceinline__ AreaQuery make_query(const QuerySource& s, int f, int i) {
+    AreaQuery q;
+    q.active = false;
+    q.x = q.y = q.r = 0.f;
+    q.min_level = q.max_level = -1;
+    if (s.mode == MODE_EXPLICIT) {
+        const OrbAreaQuery& e = s.queries[(long long)f * s.nq + i];
+        q.x = e.x;
+        q.y = e.y;
+        q.r = e.r;
+        q.min_level = e.min_level;
+        q.max_level = e.max_level;
+        q.active = true;
+        return q;
+    }
+    if (i >= s.n1[f]) return q;
+    const KpDev& k = s.kp1[(long long)f * s.nq + i];
+    const int level1 = k.octave;
+    q.r = s.r;
+    q.min_level = q.max_level = level1;
+    if (s.mode == MODE_SEARCH_INIT) {
+        if (level1 > 0) return q;  // src/ORBmatcher.cc:626-627
+        q.x = s.prev[((long long)f * s.nq + i) * 2];
+        q.y = s.prev[((long long)f * s.nq + i) * 2 + 1];
+        q.active = true;
+    } else {
+        if (!s.valid1[(long long)f * s.nq + i]) return q;          // :438-441
+        if (s.min_level > 0 && level1 < s.min_level) return q;      // :431,446-448
+        if (s.max_level < INT_MAX && level1 > s.max_level) return q;  // :432,450-452
+        q.x = k.x;
+        q.y = k.y;
+        q.active = true;
+    }
+    return q;
+}
+
+__global__ __launch_bounds__(256) void k_area_count(QuerySource s, const KpDev* __restrict__ kp2, const int32_t* __restrict__ cell_start,
+                                                    const int32_t* __restrict__ cell_items, int cap2, GridGeom gg,
+                                                    int32_t* __restrict__ counts) {
+    const int i = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+    if (i >= s.nq) return;
+    const AreaQuery q = make_query(s, f, i);
+    int c = 0;
+    if (q.active)
+        for_each_in_area(gg, kp2 + (long long)f * cap2, cell_start + (long long)f * (GRID_CELLS + 1),
+                         cell_items + (long long)f * cap2, q, [&](int) { c++; });
+    counts[(long long)f * (s.nq + 1) + i] = c;
+}
+
+// In-place exclusive scan of the nq counts of every frame (one workgroup per frame); entry nq
+// receives the frame's total, which is also written to totals[f].
+__global__ __launch_bounds__(256) void k_scan_counts(int32_t* __restrict__ counts, int nq, int32_t* __restrict__ totals) {
+    __shared__ int red[4];
+    __shared__ int carry;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int32_t* c = counts + (long long)f * (nq + 1);
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nq; base += 256) {
+        const int i = base + tid;
+        const int v = i < nq ? c[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) red[wave] = incl;
+        __syncthreads();
+        int off = carry;
+        for (int w = 0; w < wave; w++) off += red[w];
+        if (i < nq) c[i] = off + incl - v;
+        __syncthreads();
+        if (tid == 255) carry = off + incl;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        c[nq] = carry;
+        if (totals) totals[f] = carry;
+    }
+}
+
+__device__ __forceinline__ int hamming32(const uint4* __restrict__ a, const uint4* __restrict__ b) {
+    const uint4 a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+    return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) +
+           __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+// Fill pass.  out_idx (explicit queries): indices only, frame f at f*out_cap, overflow flagged.
+// out_pairs (matchers): (distance << 16 | i2) at frame_base[f] + start.
+__global__ __launch_bounds__(256) void k_area_fill(QuerySource s, const KpDev* __restrict__ kp2, const int32_t* __restrict__ cell_start,
+                                                   const int32_t* __restrict__ cell_items, int cap2, GridGeom gg,
+                                                   const int32_t* __restrict__ starts, int32_t* __restrict__ out_idx,
+                                                   int out_cap, int* __restrict__ err, const uint8_t* __restrict__ desc1,
+                                                   const uint8_t* __restrict__ desc2, const long long* __restrict__ frame_base,
+                                                   uint32_t* __restrict__ out_pairs) {
+    const int i = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+    if (i >= s.nq) return;
+    const AreaQuery q = make_query(s, f, i);
+    if (!q.active) return;
+    const int32_t* st = starts + (long long)f * (s.nq + 1);
+    int o = st[i];
+    if (out_idx) {
+        if (i == 0 && st[s.nq] > out_cap) atomicOr(err, 4);
+        int32_t* dst = out_idx + (long long)f * out_cap;
+        for_each_in_area(gg, kp2 + (long long)f * cap2, cell_start + (long long)f * (GRID_CELLS + 1),
+                         cell_items + (long long)f * cap2, q, [&](int i2) {
+                             if (o < out_cap) dst[o] = i2;
+                             o++;
+                         });
+    } else {
+        uint32_t* dst = out_pairs + frame_base[f];
+        const uint4* d1 = (const uint4*)(desc1 + ((long long)f * s.nq + i) * 32);
+        const uint8_t* d2f = desc2 + (long long)f * cap2 * 32;
+        for_each_in_area(gg, kp2 + (long long)f * cap2, cell_start + (long long)f * (GRID_CELLS + 1),
+                         cell_items + (long long)f * cap2, q, [&](int i2) {
+                             const int dist = hamming32(d1, (const uint4*)(d2f + (long long)i2 * 32));
+                             dst[o++] = ((uint32_t)dist << 16) | (uint32_t)i2;
+                         });
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Resolution: one wave per frame pair.
+__device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
+// the two smallest of the wave's keys (keys are distinct or KEY_NONE)
+__device__ __forceinline__ void wave_two_smallest(unsigned long long k1, unsigned long long k2, unsigned long long& o1,
+                                                  unsigned long long& o2) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long p1 = __shfl_xor(k1, o), p2 = __shfl_xor(k2, o);
+        // merge (k1 <= k2) with (p1 <= p2)
+        const unsigned long long lo = min(k1, p1), hi = max(k1, p1);
+        k2 = min(hi, min(k2, p2));
+        k1 = lo;
+    }
+    o1 = k1;
+    o2 = k2;
+}
+
+// bin of a match (src/ORBmatcher.cc:493-498, :679-684)
+__device__ __forceinline__ int rot_bin(float a1, float a2) {
+    const float factor = 1.0f / HISTO_LENGTH;
+    float rot = __fsub_rn(a1, a2);
+    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+    int bin = (int)round_half_away(__fmul_rn(rot, factor));
+    if (bin == HISTO_LENGTH) bin = 0;
+    return bin;
+}
+
+// ComputeThreeMaxima (src/ORBmatcher.cc:1759-1800) on the bin sizes; bit i of the result is set
+// iff bin i is one of the (up to) three kept bins.
+__device__ inline uint32_t three_maxima_mask(const int* hist) {
+    int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+        const int sz = hist[i];
+        if (sz > max1) {
+            max3 = max2;
+            max2 = max1;
+            max1 = sz;
+            ind3 = ind2;
+            ind2 = ind1;
+            ind1 = i;
+        } else if (sz > max2) {
+            max3 = max2;
+            max2 = sz;
+            ind3 = ind2;
+            ind2 = i;
+        } else if (sz > max3) {
+            max3 = sz;
+            ind3 = i;
+        }
+    }
+    if ((float)max2 < 0.1f * (float)max1) {
+        ind2 = -1;
+        ind3 = -1;
+    } else if ((float)max3 < 0.1f * (float)max1) {
+        ind3 = -1;
+    }
+    uint32_t mask = 0;
+    if (ind1 >= 0) mask |= 1u << ind1;
+    if (ind2 >= 0) mask |= 1u << ind2;
+    if (ind3 >= 0) mask |= 1u << ind3;
+    return mask;
+}
+
+// mode MODE_SEARCH_INIT or MODE_WINDOW.  LDS: four uint16 arrays of cap entries + histogram.
+template <int MODE>
+__global__ __launch_bounds__(64) void k_resolve(const KpDev* __restrict__ kp1, const int32_t* __restrict__ n1_arr,
+                                                const KpDev* __restrict__ kp2, const int32_t* __restrict__ n2_arr, int cap,
+                                                const int32_t* __restrict__ starts, const long long* __restrict__ frame_base,
+                                                const uint32_t* __restrict__ pairs, float ratio, int check_ori,
+                                                float* __restrict__ prev, int32_t* __restrict__ matches_out,
+                                                int32_t* __restrict__ nmatches_out) {
+    extern __shared__ uint16_t lds16[];
+    __shared__ int hist[HISTO_LENGTH + 2];
+    __shared__ int nm_sh;
+    const int f = blockIdx.x, lane = threadIdx.x;
+    const int n1 = min(max(n1_arr[f], 0), cap), n2 = min(max(n2_arr[f], 0), cap);
+    uint16_t* matchedDist = lds16;      // vMatchedDistance (SEARCH_INIT); NONE16 = INT_MAX
+    uint16_t* m21 = lds16 + cap;        // vnMatches21
+    uint16_t* m12 = lds16 + 2 * cap;    // vnMatches12 (SEARCH_INIT)
+    uint16_t* partner = lds16 + 3 * cap;  // SEARCH_INIT: F2 index i1 was pushed to the histogram with
+    for (int i = lane; i < cap; i += 64) {
+        matchedDist[i] = NONE16;
+        m21[i] = NONE16;
+        m12[i] = NONE16;
+        partner[i] = NONE16;
+    }
+    if (lane < HISTO_LENGTH + 2) hist[lane] = 0;
+    wave_fence();
+    const int32_t* st = starts + (long long)f * (cap + 1);
+    const uint32_t* fp = pairs + frame_base[f];
+    int nmatches = 0;
+
+    for (int c0 = 0; c0 < n1; c0 += 64) {
+        // starts of 64 keypoints at once; lane j holds those of keypoint c0 + j
+        const int ci = min(c0 + lane, n1);
+        const int my_s = st[ci], my_e = st[min(ci + 1, cap)];
+        const int chunk = min(64, n1 - c0);
+        // candidates of the first keypoint of the chunk
+        int s = __shfl(my_s, 0), e = __shfl(c0 + 1 <= n1 ? my_e : my_s, 0);
+        uint32_t cur = (s + lane < e) ? fp[s + lane] : 0u;
+        for (int j = 0; j < chunk; j++) {
+            const int i1 = c0 + j;
+            // prefetch the next keypoint's first 64 candidates
+            int ns = 0, ne = 0;
+            uint32_t nxt = 0u;
+            if (j + 1 < chunk) {
+                ns = __shfl(my_s, j + 1);
+                ne = __shfl(my_e, j + 1);
+                if (ns + lane < ne) nxt = fp[ns + lane];
+            }
+            if (s < e) {
+                unsigned long long k1 = KEY_NONE, k2 = KEY_NONE;
+                for (int b = s; b < e; b += 64) {
+                    const int p = b + lane;
+                    const uint32_t pr = (b == s) ? cur : (p < e ? fp[p] : 0u);
+                    if (p < e) {
+                        const uint32_t i2 = pr & 0xffffu, dist = pr >> 16;
+                        bool skip;
+                        if (MODE == MODE_SEARCH_INIT) skip = (uint32_t)matchedDist[i2] <= dist;  // :648
+                        else skip = m21[i2] != NONE16;                                            // :469
+                        if (!skip) {
+                            const unsigned long long key =
+                                ((unsigned long long)dist << 32) | ((unsigned long long)(uint32_t)(p - s) << 16) | i2;
+                            k2 = min(max(k1, key), k2);
+                            k1 = min(k1, key);
+                        }
+                    }
+                }
+                unsigned long long b1, b2;
+                wave_two_smallest(k1, k2, b1, b2);
+                if (b1 != KEY_NONE) {
+                    const int bestDist = (int)(b1 >> 32), bestIdx2 = (int)(b1 & 0xffffu);
+                    const float fBest2 = b2 == KEY_NONE ? (float)INT_MAX : (float)(int)(b2 >> 32);
+                    bool accept;
+                    if (MODE == MODE_SEARCH_INIT)
+                        accept = bestDist <= TH_LOW && (float)bestDist < __fmul_rn(fBest2, ratio);  // :663-665
+                    else
+                        accept = (float)bestDist <= __fmul_rn(fBest2, ratio) && bestDist <= TH_HIGH;  // :487
+                    if (accept) {
+                        if (MODE == MODE_SEARCH_INIT) {
+                            const uint32_t old = m21[bestIdx2];
+                            if (old != NONE16) nmatches--;
+                            wave_fence();
+                            if (lane == 0) {
+                                if (old != NONE16) m12[old] = NONE16;
+                                m12[i1] = (uint16_t)bestIdx2;
+                                m21[bestIdx2] = (uint16_t)i1;
+                                matchedDist[bestIdx2] = (uint16_t)bestDist;
+                                partner[i1] = (uint16_t)bestIdx2;
+                            }
+                        } else {
+                            wave_fence();
+                            if (lane == 0) m21[bestIdx2] = (uint16_t)i1;
+                        }
+                        nmatches++;
+                        wave_fence();
+                    }
+                }
+            }
+            s = ns;
+            e = ne;
+            cur = nxt;
+        }
+    }
+    wave_fence();
+
+    // ---- rotation histogram, three maxima, filter -------------------------------------------------
+    const KpDev* k1f = kp1 + (long long)f * cap;
+    const KpDev* k2f = kp2 + (long long)f * cap;
+    if (lane == 0) nm_sh = 0;
+    wave_fence();
+    if (check_ori) {
+        if (MODE == MODE_SEARCH_INIT) {
+            for (int i1 = lane; i1 < n1; i1 += 64)
+                if (partner[i1] != NONE16) atomicAdd(&hist[rot_bin(k1f[i1].angle, k2f[partner[i1]].angle)], 1);
+        } else {
+            for (int i2 = lane; i2 < n2; i2 += 64)
+                if (m21[i2] != NONE16) atomicAdd(&hist[rot_bin(k1f[m21[i2]].angle, k2f[i2].angle)], 1);
+        }
+        wave_fence();
+        const uint32_t keep = three_maxima_mask(hist);
+        int removed = 0;
+        if (MODE == MODE_SEARCH_INIT) {
+            for (int i1 = lane; i1 < n1; i1 += 64)
+                if (partner[i1] != NONE16 && !((keep >> rot_bin(k1f[i1].angle, k2f[partner[i1]].angle)) & 1u) &&
+                    m12[i1] != NONE16) {
+                    m12[i1] = NONE16;
+                    removed++;
+                }
+        } else {
+            for (int i2 = lane; i2 < n2; i2 += 64)
+                if (m21[i2] != NONE16 && !((keep >> rot_bin(k1f[m21[i2]].angle, k2f[i2].angle)) & 1u)) {
+                    m21[i2] = NONE16;
+                    removed++;
+                }
+        }
+        if (removed) atomicAdd(&nm_sh, removed);
+        wave_fence();
+    }
+    nmatches -= nm_sh;
+    if (lane == 0) nmatches_out[f] = nmatches;
+    int32_t* mo = matches_out + (long long)f * cap;
+    if (MODE == MODE_SEARCH_INIT) {
+        for (int i1 = lane; i1 < cap; i1 += 64) {
+            const uint32_t v = i1 < n1 ? m12[i1] : NONE16;
+            mo[i1] = v == NONE16 ? -1 : (int32_t)v;
+            if (v != NONE16) {  // "Update prev matched", :719-721
+                prev[((long long)f * cap + i1) * 2] = k2f[v].x;
+                prev[((long long)f * cap + i1) * 2 + 1] = k2f[v].y;
+            }
+        }
+    } else {
+        for (int i2 = lane; i2 < cap; i2 += 64) {
+            const uint32_t v = i2 < n2 ? m21[i2] : NONE16;
+            mo[i2] = v == NONE16 ? -1 : (int32_t)v;
+        }
+    }
+}
+
+GridGeom make_geom(const OrbFrameBounds& b) {
+    GridGeom g;
+    g.min_x = (float)b.min_x;
+    g.min_y = (float)b.min_y;
+    g.inv_w = static_cast<float>(GRID_COLS) / static_cast<float>(b.max_x - b.min_x);  // src/Frame.cc:78
+    g.inv_h = static_cast<float>(GRID_ROWS) / static_cast<float>(b.max_y - b.min_y);  // src/Frame.cc:79
+    return g;
+}
+
+int check_frames(orbhip_matcher* m, int batch, int cap, const OrbFrameBounds& b) {
+    if (!m) return orb_fail(ORBHIP_EINVAL, "null matcher");
+    if (batch < 0 || cap < 1) return orb_fail(ORBHIP_EINVAL, "bad batch / capacity");
+    if (cap > ORBHIP_FRAME_MAX_KEYPOINTS)
+        return orb_fail(ORBHIP_ECAP, "cap %d > %d keypoints per frame", cap, ORBHIP_FRAME_MAX_KEYPOINTS);
+    if (b.max_x <= b.min_x || b.max_y <= b.min_y) return orb_fail(ORBHIP_EINVAL, "empty image bounds");
+    return ORBHIP_OK;
+}
+
+int ensure_work(orbhip_matcher* m, size_t bytes) {
+    if (bytes <= m->work_bytes) return ORBHIP_OK;
+    if (m->d_work) hipFree(m->d_work);
+    m->d_work = nullptr;
+    m->work_bytes = 0;
+    if (hipMalloc(&m->d_work, bytes) != hipSuccess) return orb_fail(ORBHIP_ENOMEM, "hipMalloc of %zu bytes failed", bytes);
+    m->work_bytes = bytes;
+    return ORBHIP_OK;
+}
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// Shared body of the two matchers.
+int run_matcher(orbhip_matcher* m, int mode, const OrbKeypoint* d_kp1, const uint8_t* d_desc1, const int32_t* d_n1,
+                const uint8_t* d_valid1, const OrbKeypoint* d_kp2, const uint8_t* d_desc2, const int32_t* d_n2,
+                const int32_t* d_cell_start2, const int32_t* d_cell_items2, int batch, int cap, OrbFrameBounds bounds,
+                float* d_prev, int window_size, int min_level, int max_level, float ratio, int check_ori,
+                int32_t* d_matches, int32_t* d_nmatches) {
+    int rc = check_frames(m, batch, cap, bounds);
+    if (rc) return rc;
+    if (batch == 0) return ORBHIP_OK;
+    if (!d_kp1 || !d_desc1 || !d_n1 || !d_kp2 || !d_desc2 || !d_n2 || !d_cell_start2 || !d_cell_items2 || !d_matches ||
+        !d_nmatches || (mode == MODE_SEARCH_INIT && !d_prev) || (mode == MODE_WINDOW && !d_valid1))
+        return orb_fail(ORBHIP_EINVAL, "null buffer");
+    HIPCHK(hipSetDevice(m->device));
+    (void)hipGetLastError();
+    const GridGeom gg = make_geom(bounds);
+    QuerySource s;
+    s.mode = mode;
+    s.queries = nullptr;
+    s.kp1 = (const KpDev*)d_kp1;
+    s.n1 = d_n1;
+    s.prev = d_prev;
+    s.valid1 = d_valid1;
+    s.r = (float)window_size;  // int windowSize binds to "const float &r"
+    s.min_level = min_level;
+    s.max_level = max_level;
+    s.nq = cap;
+    // workspace: starts [batch*(cap+1)] | totals [batch] | frame_base [batch] (int64) | pairs
+    const size_t off_tot = align256(sizeof(int32_t) * (size_t)batch * (cap + 1));
+    const size_t off_base = off_tot + align256(sizeof(int32_t) * (size_t)batch);
+    const size_t off_pairs = off_base + align256(sizeof(long long) * (size_t)batch);
+    if ((rc = ensure_work(m, off_pairs))) return rc;
+    HIPCHK(hipEventRecord(m->ev0, m->stream));
+    dim3 qgrid((cap + 255) / 256, batch);
+    {
+        int32_t* starts = (int32_t*)m->d_work;
+        int32_t* totals = (int32_t*)((char*)m->d_work + off_tot);
+        hipLaunchKernelGGL(k_area_count, qgrid, dim3(256), 0, m->stream, s, (const KpDev*)d_kp2, d_cell_start2, d_cell_items2,
+                           cap, gg, starts);
+        hipLaunchKernelGGL(k_scan_counts, dim3(batch), dim3(256), 0, m->stream, starts, cap, totals);
+    }
+    std::vector<int32_t> totals(batch);
+    HIPCHK(hipMemcpyAsync(totals.data(), (char*)m->d_work + off_tot, sizeof(int32_t) * batch, hipMemcpyDeviceToHost,
+                          m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    std::vector<long long> base(batch);
+    long long total = 0;
+    for (int f = 0; f < batch; f++) {
+        base[f] = total;
+        total += totals[f];
+    }
+    // growing the workspace moves it: keep what the count pass produced
+    const size_t need = off_pairs + sizeof(uint32_t) * (size_t)std::max<long long>(total, 1);
+    if (need > m->work_bytes) {
+        void* old = m->d_work;
+        const size_t old_bytes = m->work_bytes;
+        m->d_work = nullptr;
+        m->work_bytes = 0;
+        if ((rc = ensure_work(m, need + need / 4))) {
+            hipFree(old);
+            return rc;
+        }
+        hipError_t ce = hipMemcpy(m->d_work, old, std::min(old_bytes, off_pairs), hipMemcpyDeviceToDevice);
+        hipFree(old);
+        if (ce != hipSuccess) return orb_fail(ORBHIP_EHIP, "workspace copy failed: %s", hipGetErrorString(ce));
+    }
+    int32_t* starts = (int32_t*)m->d_work;
+    long long* d_base = (long long*)((char*)m->d_work + off_base);
+    uint32_t* pairs = (uint32_t*)((char*)m->d_work + off_pairs);
+    HIPCHK(hipMemcpyAsync(d_base, base.data(), sizeof(long long) * batch, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));  // `base` is a stack-lifetime host buffer
+    hipLaunchKernelGGL(k_area_fill, qgrid, dim3(256), 0, m->stream, s, (const KpDev*)d_kp2, d_cell_start2, d_cell_items2, cap,
+                       gg, starts, (int32_t*)nullptr, 0, m->d_err, d_desc1, d_desc2, d_base, pairs);
+    const size_t lds = sizeof(uint16_t) * 4 * (size_t)cap;
+    if (mode == MODE_SEARCH_INIT) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_resolve<MODE_SEARCH_INIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_resolve<MODE_SEARCH_INIT>, dim3(batch), dim3(64), lds, m->stream, (const KpDev*)d_kp1, d_n1,
+                           (const KpDev*)d_kp2, d_n2, cap, starts, d_base, pairs, ratio, check_ori, d_prev, d_matches,
+                           d_nmatches);
+    } else {
+        HIPCHK(hipFuncSetAttribute((const void*)k_resolve<MODE_WINDOW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_resolve<MODE_WINDOW>, dim3(batch), dim3(64), lds, m->stream, (const KpDev*)d_kp1, d_n1,
+                           (const KpDev*)d_kp2, d_n2, cap, starts, d_base, pairs, ratio, check_ori, d_prev, d_matches,
+                           d_nmatches);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(m->ev1, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return ORBHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int orbhip_frame_grid_device(orbhip_matcher* m, const OrbKeypoint* d_kp, const int32_t* d_n, int batch, int cap,
+                             OrbFrameBounds bounds, int32_t* d_cell_start, int32_t* d_cell_items) {
+    int rc = check_frames(m, batch, cap, bounds);
+    if (rc) return rc;
+    if (batch == 0) return ORBHIP_OK;
+    if (!d_kp || !d_n || !d_cell_start || !d_cell_items) return orb_fail(ORBHIP_EINVAL, "null buffer");
+    HIPCHK(hipSetDevice(m->device));
+    (void)hipGetLastError();
+    int np2 = 64;
+    while (np2 < cap) np2 <<= 1;
+    hipLaunchKernelGGL(k_frame_grid, dim3(batch), dim3(GB_THREADS), sizeof(uint32_t) * (size_t)np2, m->stream, (const KpDev*)d_kp,
+                       d_n, cap, make_geom(bounds), d_cell_start, d_cell_items);
+    HIPCHK(hipGetLastError());
+    return ORBHIP_OK;
+}
+
+int orbhip_features_in_area_device(orbhip_matcher* m, const OrbKeypoint* d_kp, const int32_t* d_n, int batch, int cap,
+                                   OrbFrameBounds bounds, const int32_t* d_cell_start, const int32_t* d_cell_items,
+                                   const OrbAreaQuery* d_queries, int nq, int32_t* d_out_start, int32_t* d_out,
+                                   int out_cap) {
+    int rc = check_frames(m, batch, cap, bounds);
+    if (rc) return rc;
+    if (nq < 0 || out_cap < 0) return orb_fail(ORBHIP_EINVAL, "negative size");
+    if (batch == 0) return ORBHIP_OK;
+    if (!d_kp || !d_n || !d_cell_start || !d_cell_items || !d_out_start || (nq && !d_queries) || (out_cap && !d_out))
+        return orb_fail(ORBHIP_EINVAL, "null buffer");
+    HIPCHK(hipSetDevice(m->device));
+    (void)hipGetLastError();
+    QuerySource s;
+    s.mode = MODE_EXPLICIT;
+    s.queries = d_queries;
+    s.kp1 = nullptr;
+    s.n1 = nullptr;
+    s.prev = nullptr;
+    s.valid1 = nullptr;
+    s.r = 0.f;
+    s.min_level = s.max_level = -1;
+    s.nq = nq;
+    const GridGeom gg = make_geom(bounds);
+    dim3 qgrid((std::max(nq, 1) + 255) / 256, batch);
+    if (nq)
+        hipLaunchKernelGGL(k_area_count, qgrid, dim3(256), 0, m->stream, s, (const KpDev*)d_kp, d_cell_start, d_cell_items, cap,
+                           gg, d_out_start);
+    hipLaunchKernelGGL(k_scan_counts, dim3(batch), dim3(256), 0, m->stream, d_out_start, nq, (int32_t*)nullptr);
+    if (nq)
+        hipLaunchKernelGGL(k_area_fill, qgrid, dim3(256), 0, m->stream, s, (const KpDev*)d_kp, d_cell_start, d_cell_items, cap,
+                           gg, d_out_start, d_out, out_cap, m->d_err, (const uint8_t*)nullptr, (const uint8_t*)nullptr,
+                           (const long long*)nullptr, (uint32_t*)nullptr);
+    HIPCHK(hipGetLastError());
+    return ORBHIP_OK;
+}
+
+int orbhip_search_for_initialization_device(orbhip_matcher* m, const OrbKeypoint* d_kp1, const uint8_t* d_desc1,
+                                            const int32_t* d_n1, const OrbKeypoint* d_kp2, const uint8_t* d_desc2,
+                                            const int32_t* d_n2, const int32_t* d_cell_start2,
+                                            const int32_t* d_cell_items2, int batch, int cap, OrbFrameBounds bounds,
+                                            float* d_prev_matched, int window_size, float nnratio,
+                                            int check_orientation, int32_t* d_matches12, int32_t* d_nmatches) {
+    return run_matcher(m, MODE_SEARCH_INIT, d_kp1, d_desc1, d_n1, nullptr, d_kp2, d_desc2, d_n2, d_cell_start2, d_cell_items2,
+                       batch, cap, bounds, d_prev_matched, window_size, -1, INT_MAX, nnratio, check_orientation, d_matches12,
+                       d_nmatches);
+}
+
+int orbhip_window_search_device(orbhip_matcher* m, const OrbKeypoint* d_kp1, const uint8_t* d_desc1,
+                                const int32_t* d_n1, const uint8_t* d_valid1, const OrbKeypoint* d_kp2,
+                                const uint8_t* d_desc2, const int32_t* d_n2, const int32_t* d_cell_start2,
+                                const int32_t* d_cell_items2, int batch, int cap, OrbFrameBounds bounds,
+                                int window_size, int min_level, int max_level, float nnratio, int check_orientation,
+                                int32_t* d_matches21, int32_t* d_nmatches) {
+    return run_matcher(m, MODE_WINDOW, d_kp1, d_desc1, d_n1, d_valid1, d_kp2, d_desc2, d_n2, d_cell_start2, d_cell_items2,
+                       batch, cap, bounds, nullptr, window_size, min_level, max_level, nnratio, check_orientation,
+                       d_matches21, d_nmatches);
+}
+
+}  // extern "C"

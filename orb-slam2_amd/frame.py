@@ -1,0 +1,81 @@
+"""Host-side mirror of the part of ORB_SLAM::Frame the windowed matchers use (include/Frame.h:37-38,
+90-92, src/Frame.cc:78-79,110-124,201-278): the undistorted keypoints, the descriptors and the
+64 x 48 feature grid, for a batch of independent frames resident in device memory.
+
+torch tensors are plumbing only (device memory); every computation is a call into liborbhip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+FRAME_GRID_ROWS = 48  # include/Frame.h:37
+FRAME_GRID_COLS = 64  # include/Frame.h:38
+GRID_CELLS = FRAME_GRID_ROWS * FRAME_GRID_COLS
+
+AREA_QUERY_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("r", "<f4"), ("min_level", "<i4"), ("max_level", "<i4")])
+
+
+class FrameBatch:
+    """`batch` frames: keypoint records [batch, cap] (28 B each, as the extractor writes them),
+    descriptors [batch, cap, 32] u8, counts [batch] i32 — torch CUDA tensors — plus the image bounds
+    (mnMinX, mnMinY, mnMaxX, mnMaxY).  The grid is built on construction like the reference's Frame
+    constructor does."""
+
+    def __init__(self, matcher, kp, desc, n, bounds):
+        import torch
+        self._m = matcher
+        self.kp, self.desc, self.n = kp, desc, n
+        self.batch, self.cap = int(n.shape[0]), int(desc.shape[1])
+        assert kp.is_cuda and desc.is_cuda and n.is_cuda and n.dtype == torch.int32
+        assert kp.numel() * kp.element_size() == self.batch * self.cap * 28
+        self.bounds = _lib.OrbFrameBounds(*[int(b) for b in bounds])
+        self.cell_start = torch.zeros((self.batch, GRID_CELLS + 1), dtype=torch.int32, device=n.device)
+        self.cell_items = torch.zeros((self.batch, self.cap), dtype=torch.int32, device=n.device)
+        L = _lib.lib()
+        torch.cuda.synchronize()
+        _lib.check(L.orbhip_frame_grid_device(matcher._h, kp.data_ptr(), n.data_ptr(), self.batch, self.cap, self.bounds,
+                                              self.cell_start.data_ptr(), self.cell_items.data_ptr()))
+        matcher.synchronize()
+
+    @classmethod
+    def from_host(cls, matcher, kps, descs, bounds, cap=None, device="cuda:0"):
+        """kps: list of structured keypoint arrays, descs: list of [n, 32] u8 arrays."""
+        import torch
+        batch = len(kps)
+        cap = cap or max(1, max(len(k) for k in kps))
+        kp = np.zeros((batch, cap, 7), np.float32)
+        de = np.zeros((batch, cap, 32), np.uint8)
+        n = np.zeros(batch, np.int32)
+        for f, (k, d) in enumerate(zip(kps, descs)):
+            n[f] = len(k)
+            if len(k):
+                kp[f, :len(k)] = np.ascontiguousarray(k).view(np.float32).reshape(len(k), 7)
+                de[f, :len(k)] = d
+        return cls(matcher, torch.from_numpy(kp).to(device), torch.from_numpy(de).to(device),
+                   torch.from_numpy(n).to(device), bounds)
+
+    def grid(self, f):
+        """(cell_start[3073], items) of frame f on the host; cell = ix*48 + iy."""
+        cs = self.cell_start[f].cpu().numpy()
+        return cs, self.cell_items[f, :cs[-1]].cpu().numpy()
+
+    def GetFeaturesInArea(self, queries, out_cap=None):
+        """Batched Frame::GetFeaturesInArea.  queries: [batch, nq] array of AREA_QUERY_DTYPE.
+        Returns (starts [batch, nq+1], indices [batch, out_cap]) as host arrays."""
+        import torch
+        q = np.ascontiguousarray(queries, dtype=AREA_QUERY_DTYPE).reshape(self.batch, -1)
+        nq = q.shape[1]
+        out_cap = out_cap or max(1, nq * self.cap)
+        dev = self.n.device
+        d_q = torch.from_numpy(q.view(np.uint8).reshape(self.batch, -1)).to(dev)
+        d_start = torch.zeros((self.batch, nq + 1), dtype=torch.int32, device=dev)
+        d_out = torch.zeros((self.batch, out_cap), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        _lib.check(_lib.lib().orbhip_features_in_area_device(
+            self._m._h, self.kp.data_ptr(), self.n.data_ptr(), self.batch, self.cap, self.bounds,
+            self.cell_start.data_ptr(), self.cell_items.data_ptr(), d_q.data_ptr(), nq, d_start.data_ptr(),
+            d_out.data_ptr(), out_cap))
+        self._m.synchronize()
+        return d_start.cpu().numpy(), d_out.cpu().numpy()

@@ -74,6 +74,46 @@ class ORBmatcher:
         r = self.mfNNratio if ratio is None else ratio
         _lib.check(self._L.orbhip_ratio_test_device(self._h, d_d1, d_d2, n, r, form, th, d_accept))
 
+    def SearchForInitialization(self, F1, F2, vbPrevMatched, windowSize=10):
+        """int SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f> &vbPrevMatched,
+        vector<int> &vnMatches12, int windowSize=10) (include/ORBmatcher.h:76, src/ORBmatcher.cc:609-724)
+        for every frame pair of two FrameBatch objects.  vbPrevMatched: float32 CUDA tensor
+        [batch, cap, 2], updated in place.  Returns (nmatches [batch], vnMatches12 [batch, cap]) as
+        int32 CUDA tensors."""
+        import torch
+        assert F1.batch == F2.batch and F1.cap == F2.cap
+        assert vbPrevMatched.is_cuda and vbPrevMatched.dtype == torch.float32 and vbPrevMatched.is_contiguous()
+        dev = F1.n.device
+        m12 = torch.empty((F1.batch, F1.cap), dtype=torch.int32, device=dev)
+        nm = torch.empty(F1.batch, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        _lib.check(self._L.orbhip_search_for_initialization_device(
+            self._h, F1.kp.data_ptr(), F1.desc.data_ptr(), F1.n.data_ptr(), F2.kp.data_ptr(), F2.desc.data_ptr(),
+            F2.n.data_ptr(), F2.cell_start.data_ptr(), F2.cell_items.data_ptr(), F1.batch, F1.cap, F2.bounds,
+            vbPrevMatched.data_ptr(), int(windowSize), self.mfNNratio, int(self.mbCheckOrientation), m12.data_ptr(),
+            nm.data_ptr()))
+        return nm, m12
+
+    def WindowSearch(self, F1, F2, windowSize, valid1, minScaleLevel=-1, maxScaleLevel=INT_MAX):
+        """int WindowSearch(Frame &F1, Frame &F2, int windowSize, vector<MapPoint*> &vpMapPointMatches2,
+        int minScaleLevel=-1, int maxScaleLevel=INT_MAX) (include/ORBmatcher.h:71, src/ORBmatcher.cc:420-527).
+        valid1: uint8 CUDA tensor [batch, cap], non-zero where F1.mvpMapPoints[i] is a good map point.
+        Returns (nmatches [batch], vnMatches21 [batch, cap]): vpMapPointMatches2[i2] =
+        F1.mvpMapPoints[vnMatches21[i2]] where that is >= 0."""
+        import torch
+        assert F1.batch == F2.batch and F1.cap == F2.cap
+        assert valid1.is_cuda and valid1.dtype == torch.uint8 and valid1.is_contiguous()
+        dev = F1.n.device
+        m21 = torch.empty((F1.batch, F1.cap), dtype=torch.int32, device=dev)
+        nm = torch.empty(F1.batch, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        _lib.check(self._L.orbhip_window_search_device(
+            self._h, F1.kp.data_ptr(), F1.desc.data_ptr(), F1.n.data_ptr(), valid1.data_ptr(), F2.kp.data_ptr(),
+            F2.desc.data_ptr(), F2.n.data_ptr(), F2.cell_start.data_ptr(), F2.cell_items.data_ptr(), F1.batch, F1.cap,
+            F2.bounds, int(windowSize), int(minScaleLevel), int(maxScaleLevel), self.mfNNratio,
+            int(self.mbCheckOrientation), m21.data_ptr(), nm.data_ptr()))
+        return nm, m21
+
     def valu_rate(self, mode):
         """Sustained lane-ops/s of v_bcnt (0), the xor+bcnt mix (1) or v_add (2) on this device."""
         return float(self._L.orbhip_valu_rate(self._h, mode))

@@ -1,0 +1,126 @@
+"""Known-answer tests of the oracle's frame grid, GetFeaturesInArea and windowed matchers
+(oracle/frame_ref.cpp).  The reference holds no tests or fixtures for this path (parity
+unpinned), so the expected values below are derived by hand from src/Frame.cc:201-278 and
+src/ORBmatcher.cc:420-527,609-724."""
+import numpy as np
+
+INT_MAX = 2147483647
+B640 = [0, 0, 640, 480]  # mfGridElementWidthInv = 64/640 = 0.1, mfGridElementHeightInv = 48/480 = 0.1
+
+
+def kps(orbref, pts, octave=0, angle=0.0):
+    kp = np.zeros(len(pts), orbref.KP_DTYPE)
+    for i, p in enumerate(pts):
+        kp["x"][i], kp["y"][i] = p[0], p[1]
+        kp["octave"][i] = p[2] if len(p) > 2 else octave
+        kp["angle"][i] = p[3] if len(p) > 3 else angle
+    return kp
+
+
+def bits(k):
+    d = np.zeros(32, np.uint8)
+    for i in range(k):
+        d[i // 8] |= np.uint8(1 << (i % 8))
+    return d
+
+
+def test_pos_in_grid_rounds_half_away_and_rejects_the_far_edge(orbref):
+    # x*0.1: 1.49 -> 1, 1.5 -> 2 (std::round), 63.5 -> 64 = FRAME_GRID_COLS -> in no cell; y 47.5 -> 48 -> none
+    kp = kps(orbref, [(14.9, 0), (15.0, 0), (635.0, 10), (634.9, 10), (20, 475.0), (20, 474.9), (-5.1, 0), (-4.9, 0)])
+    start, items = orbref.frame_grid(kp, B640)
+    cell = {}
+    for c in range(64 * 48):
+        for i in items[start[c]:start[c + 1]]:
+            cell[int(i)] = (c // 48, c % 48)
+    assert cell == {0: (1, 0), 1: (2, 0), 3: (63, 1), 5: (2, 47), 7: (0, 0)}
+    assert start[-1] == 5
+
+
+def test_grid_items_keep_push_order(orbref):
+    kp = kps(orbref, [(100, 100)] * 5 + [(50, 50)] * 2)
+    start, items = orbref.frame_grid(kp, B640)
+    assert list(items) == [5, 6, 0, 1, 2, 3, 4]  # cell (5,5) precedes cell (10,10)
+
+
+def test_features_in_area_order_levels_and_closed_window(orbref):
+    # index order deliberately differs from grid order: result is grid-column major, row minor
+    kp = kps(orbref, [(100, 130, 0), (130, 100, 1), (100, 100, 0), (135, 100, 0), (135.5, 100, 0)])
+    assert list(orbref.features_in_area(kp, B640, 115.0, 115.0, 20.0)) == [2, 0, 1, 3]  # |dx| = 20 is inside, 20.5 is not
+    assert list(orbref.features_in_area(kp, B640, 115.0, 115.0, 20.0, 0, 0)) == [2, 0, 3]
+    assert list(orbref.features_in_area(kp, B640, 115.0, 115.0, 20.0, 1, 3)) == [1]
+    assert list(orbref.features_in_area(kp, B640, 115.0, 115.0, 14.0)) == []
+    assert list(orbref.features_in_area(kp, B640, 2000.0, 115.0, 20.0)) == []   # nMinCellX >= FRAME_GRID_COLS
+    assert list(orbref.features_in_area(kp, B640, -500.0, 115.0, 20.0)) == []   # nMaxCellX < 0
+
+
+def test_search_for_initialization_later_keypoint_steals_or_is_blocked(orbref):
+    kp2 = kps(orbref, [(100, 100)])
+    d2 = np.stack([bits(0)])
+    kp1 = kps(orbref, [(101, 100), (99, 100)])
+    prev = np.array([[101, 100], [99, 100]], np.float32)
+    # distances 10 then 5: the second takes the feature, the first loses it
+    n, m12, pv = orbref.search_for_initialization(kp1, np.stack([bits(10), bits(5)]), kp2, d2, B640, prev, 100, 0.9, False)
+    assert n == 1 and list(m12) == [-1, 0]
+    assert pv[1, 0] == 100 and pv[0, 0] == 101
+    # distances 10 then 12: vMatchedDistance[0] = 10 <= 12 blocks the candidate
+    n, m12, _ = orbref.search_for_initialization(kp1, np.stack([bits(10), bits(12)]), kp2, d2, B640, prev, 100, 0.9, False)
+    assert n == 1 and list(m12) == [0, -1]
+    # TH_LOW = 20 is inclusive; 21 is rejected
+    n, m12, _ = orbref.search_for_initialization(kp1[:1], np.stack([bits(20)]), kp2, d2, B640, prev[:1], 100, 0.9, False)
+    assert n == 1
+    n, m12, _ = orbref.search_for_initialization(kp1[:1], np.stack([bits(21)]), kp2, d2, B640, prev[:1], 100, 0.9, False)
+    assert n == 0
+    # only level-0 keypoints of F1 are matched
+    n, _, _ = orbref.search_for_initialization(kps(orbref, [(101, 100, 1)]), np.stack([bits(3)]), kp2, d2, B640, prev[:1], 100, 0.9, False)
+    assert n == 0
+
+
+def test_search_for_initialization_ratio_is_strict(orbref):
+    kp2 = kps(orbref, [(100, 100), (102, 100)])
+    kp1 = kps(orbref, [(101, 100)])
+    prev = np.array([[101, 100]], np.float32)
+    # best 9, second 10: 9 < 10 * 0.9 is false
+    n, _, _ = orbref.search_for_initialization(kp1, np.stack([bits(0)]), kp2, np.stack([bits(9), bits(10)]), B640, prev, 100, 0.9, False)
+    assert n == 0
+    n, m12, _ = orbref.search_for_initialization(kp1, np.stack([bits(0)]), kp2, np.stack([bits(8), bits(10)]), B640, prev, 100, 0.9, False)
+    assert n == 1 and m12[0] == 0
+
+
+def test_window_search_skips_taken_features_and_accepts_equal_ratio(orbref):
+    kp2 = kps(orbref, [(100, 100), (104, 100)])
+    d2 = np.stack([bits(0), bits(6)])
+    kp1 = kps(orbref, [(101, 100), (102, 100)])
+    d1 = np.stack([bits(0), bits(0)])
+    v = np.ones(2, np.uint8)
+    # first keypoint: 0 <= 6*0.6 takes feature 0; second: feature 0 taken, feature 1 alone (d2 = INT_MAX) accepted
+    n, m21 = orbref.window_search(kp1, d1, v, kp2, d2, B640, 50, -1, INT_MAX, 0.6, False)
+    assert n == 2 and list(m21) == [0, 1]
+    # a keypoint without a good map point is not matched
+    n, m21 = orbref.window_search(kp1, d1, np.array([0, 1], np.uint8), kp2, d2, B640, 50, -1, INT_MAX, 0.6, False)
+    assert n == 1 and list(m21) == [1, -1]
+    # "bestDist <= bestDist2 * ratio" is not strict: 6 <= 10 * 0.6
+    n, m21 = orbref.window_search(kp1[:1], np.stack([bits(0)]), v[:1], kp2, np.stack([bits(6), bits(10)]), B640, 50, -1, INT_MAX, 0.6, False)
+    assert n == 1 and m21[0] == 0
+    # minScaleLevel = 1 filters level-0 keypoints of F1; minScaleLevel = 0 does not filter
+    n, _ = orbref.window_search(kp1, d1, v, kp2, d2, B640, 50, 1, INT_MAX, 0.6, False)
+    assert n == 0
+
+
+def test_rotation_histogram_drops_the_outlier_bin(orbref):
+    # 12 matches with rotation 3 deg (bin round(0.1) = 0), one with 100 deg (bin round(3.33) = 3):
+    # max2 = 1 < 0.1 * 12 -> only bin 0 survives
+    n = 13
+    pts = [(40 * (i % 8) + 60, 60 * (i // 8) + 60) for i in range(n)]
+    kp1 = kps(orbref, [(x, y, 0, 103.0 if i < 12 else 200.0) for i, (x, y) in enumerate(pts)])
+    kp2 = kps(orbref, [(x, y, 0, 100.0) for (x, y) in pts])
+    rng = np.random.default_rng(1)
+    d = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    prev = np.array(pts, np.float32)
+    nm, m12, _ = orbref.search_for_initialization(kp1, d, kp2, d, B640, prev, 10, 0.9, True)
+    assert nm == 12 and list(m12) == list(range(12)) + [-1]
+    nm, m12, _ = orbref.search_for_initialization(kp1, d, kp2, d, B640, prev, 10, 0.9, False)
+    assert nm == 13
+    nm, m21 = orbref.window_search(kp1, d, np.ones(n, np.uint8), kp2, d, B640, 10, -1, INT_MAX, 0.6, True)
+    assert nm == 12 and m21[12] == -1
+    # negative difference wraps: 10 - 100 + 360 = 270 -> bin 9
+    assert orbref.lib().orbref_rot_bin(10.0, 100.0) == 9
