@@ -320,7 +320,77 @@ def extra_legs(orb, torch, dev, threads):
                            "cpu_oracle_1_thread_comparisons_per_sec": float("%.4g" % (nq * nt / cdt)),
                            "parity_pair0": bool(np.array_equal(oo[0], ridx) and np.array_equal(oo[1], rd1)
                                                 and np.array_equal(oo[2], rd2))}
+    res["windowed_matchers"] = windowed_leg(orb, torch, dev, orbref)
     return res
+
+
+def windowed_leg(orb, torch, dev, orbref):
+    """Frame grid + SearchForInitialization(window 100) + WindowSearch(window 100) over 256 frame pairs
+    of ~2000 keypoints (extractor output of 1280x720 frames; F2 = F1 jittered by up to 8 px with ~8
+    descriptor bits flipped), next to the oracle on one thread for the first 4 pairs."""
+    b, w, h, nf = 256, 1280, 720, 2000
+    wl = ExtractWorkload(orb, torch, dev, w, h, nf, b, first_idx=200000)
+    wl.step()
+    wl.sync()
+    g = torch.Generator(device="cuda:%d" % dev)
+    g.manual_seed(7)
+    cuda = "cuda:%d" % dev
+    kp1 = wl.d_kp.view(torch.uint8).view(b, nf, 28).clone()
+    kp2 = kp1.clone()
+    xy = kp2.view(torch.float32).view(b, nf, 7)
+    xy[:, :, 0:2] += torch.rand((b, nf, 2), device=cuda, generator=g) * 16 - 8
+    d1 = wl.d_desc.view(b, nf, 32).clone()
+    flips = torch.randint(0, 256, (b, nf, 32), dtype=torch.uint8, device=cuda, generator=g)
+    for _ in range(4):  # each bit survives five ANDs with probability 1/32: ~8 of 256 bits flipped
+        flips &= torch.randint(0, 256, (b, nf, 32), dtype=torch.uint8, device=cuda, generator=g)
+    d2 = d1 ^ flips
+    n = wl.d_n.clone()
+    bounds = [0, 0, w, h]
+    m_init, m_win = orb.ORBmatcher(0.9, True, device=dev), orb.ORBmatcher(0.6, True, device=dev)
+    t0 = time.perf_counter()
+    F1 = orb.FrameBatch(m_init, kp1, d1, n, bounds)
+    F2 = orb.FrameBatch(m_init, kp2, d2, n, bounds)
+    t_grid = (time.perf_counter() - t0) / 2
+    prev0 = kp1.view(torch.float32).view(b, nf, 7)[:, :, 0:2].contiguous()
+    valid = torch.ones((b, nf), dtype=torch.uint8, device=cuda)
+    out = {}
+    for name, fn in (("search_for_initialization_w100", lambda: m_init.SearchForInitialization(F1, F2, prev0.clone(), 100)),
+                     ("window_search_w100", lambda: m_win.WindowSearch(F1, F2, 100, valid, 0))):
+        fn()
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            nm, mm = fn()
+            torch.cuda.synchronize(dev)
+            ts.append(time.perf_counter() - t0)
+        out[name] = {"pairs_per_sec": round(b / float(np.median(ts)), 1), "ms_per_%d_pairs" % b: round(float(np.median(ts)) * 1e3, 3),
+                     "mean_matches_per_pair": round(float(nm.float().mean().item()), 1)}
+    # oracle, one thread, first 4 pairs (+ parity of those)
+    hk1, hk2 = kp1[:4].cpu().numpy().view(orbref.KP_DTYPE).reshape(4, nf), kp2[:4].cpu().numpy().view(orbref.KP_DTYPE).reshape(4, nf)
+    hd1, hd2, hn = d1[:4].cpu().numpy(), d2[:4].cpu().numpy(), n[:4].cpu().numpy()
+    nm_i, m12 = m_init.SearchForInitialization(F1, F2, prev0.clone(), 100)
+    nm_w, m21 = m_win.WindowSearch(F1, F2, 100, valid, 0)
+    m12, m21 = m12[:4].cpu().numpy(), m21[:4].cpu().numpy()
+    ok = True
+    t_i = t_w = 0.0
+    for f in range(4):
+        k = int(hn[f])
+        pv = np.stack([hk1[f, :k]["x"], hk1[f, :k]["y"]], 1)
+        t0 = time.perf_counter()
+        rn, r12, _ = orbref.search_for_initialization(hk1[f, :k], hd1[f, :k], hk2[f, :k], hd2[f, :k], bounds, pv, 100,
+                                                      m_init.mfNNratio, True)
+        t_i += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        rw, r21 = orbref.window_search(hk1[f, :k], hd1[f, :k], np.ones(k, np.uint8), hk2[f, :k], hd2[f, :k], bounds, 100, 0,
+                                       2**31 - 1, m_win.mfNNratio, True)
+        t_w += time.perf_counter() - t0
+        ok = ok and np.array_equal(r12, m12[f, :k]) and np.array_equal(r21, m21[f, :k])
+    out["frame_grid_ms_per_%d_frames" % b] = round(t_grid * 1e3, 3)
+    out["cpu_oracle_1_thread_pairs_per_sec"] = {"search_for_initialization_w100": round(4 / t_i, 1),
+                                                "window_search_w100": round(4 / t_w, 1)}
+    out["parity_first_4_pairs"] = bool(ok)
+    return out
 
 
 if __name__ == "__main__":

@@ -221,6 +221,18 @@ int orbhip_window_search_device(orbhip_matcher* m, const OrbKeypoint* d_kp1, con
                                 int window_size, int min_level, int max_level, float nnratio, int check_orientation,
                                 int32_t* d_matches21, int32_t* d_nmatches);
 
+/* Host-pointer forms of the two matchers for ONE frame pair (copy in, build F2's grid, match, copy
+ * out; blocking) — what a forwarding ORBmatcher::SearchForInitialization / WindowSearch calls with
+ * the contents of F1.mvKeysUn / mDescriptors and F2's. */
+int orbhip_search_for_initialization(orbhip_matcher* m, const OrbKeypoint* kp1, const uint8_t* desc1, int n1,
+                                     const OrbKeypoint* kp2, const uint8_t* desc2, int n2, OrbFrameBounds bounds,
+                                     float* prev_matched, int window_size, float nnratio, int check_orientation,
+                                     int32_t* matches12, int32_t* nmatches);
+int orbhip_window_search(orbhip_matcher* m, const OrbKeypoint* kp1, const uint8_t* desc1, int n1, const uint8_t* valid1,
+                         const OrbKeypoint* kp2, const uint8_t* desc2, int n2, OrbFrameBounds bounds, int window_size,
+                         int min_level, int max_level, float nnratio, int check_orientation, int32_t* matches21,
+                         int32_t* nmatches);
+
 /* Device self-tests of the arithmetic helpers (test instrumentation, host pointers, blocking):
  * which 0: n (y, x) float pairs -> n floats, the device's fastAtan2 in degrees
  *       1: n float angles (radians) -> n (cos, sin) float pairs as the descriptor kernel computes them

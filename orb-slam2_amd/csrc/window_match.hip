@@ -718,3 +718,124 @@ int orbhip_window_search_device(orbhip_matcher* m, const OrbKeypoint* d_kp1, con
 }
 
 }  // extern "C"
+
+namespace {
+
+// Host-pointer forms: one frame pair, copies in and out through a staging arena of the handle.
+struct PairStage {
+    OrbKeypoint *kp1, *kp2;
+    uint8_t *desc1, *desc2, *valid1;
+    int32_t *n, *cell_start, *cell_items, *matches, *nmatches;
+    float* prev;
+};
+
+int stage_pair(orbhip_matcher* m, int cap, PairStage& ps) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off += align256(bytes);
+        return o;
+    };
+    const size_t o_kp1 = take(sizeof(OrbKeypoint) * cap), o_kp2 = take(sizeof(OrbKeypoint) * cap);
+    const size_t o_d1 = take(32 * (size_t)cap), o_d2 = take(32 * (size_t)cap), o_v = take(cap);
+    const size_t o_n = take(sizeof(int32_t) * 2), o_cs = take(sizeof(int32_t) * (GRID_CELLS + 1));
+    const size_t o_ci = take(sizeof(int32_t) * cap), o_m = take(sizeof(int32_t) * cap), o_nm = take(sizeof(int32_t));
+    const size_t o_prev = take(sizeof(float) * 2 * cap);
+    if (off > m->stage_bytes) {
+        if (m->d_stage) hipFree(m->d_stage);
+        m->d_stage = nullptr;
+        m->stage_bytes = 0;
+        if (hipMalloc(&m->d_stage, off) != hipSuccess) return orb_fail(ORBHIP_ENOMEM, "hipMalloc of %zu bytes failed", off);
+        m->stage_bytes = off;
+    }
+    char* b = (char*)m->d_stage;
+    ps.kp1 = (OrbKeypoint*)(b + o_kp1);
+    ps.kp2 = (OrbKeypoint*)(b + o_kp2);
+    ps.desc1 = (uint8_t*)(b + o_d1);
+    ps.desc2 = (uint8_t*)(b + o_d2);
+    ps.valid1 = (uint8_t*)(b + o_v);
+    ps.n = (int32_t*)(b + o_n);
+    ps.cell_start = (int32_t*)(b + o_cs);
+    ps.cell_items = (int32_t*)(b + o_ci);
+    ps.matches = (int32_t*)(b + o_m);
+    ps.nmatches = (int32_t*)(b + o_nm);
+    ps.prev = (float*)(b + o_prev);
+    return ORBHIP_OK;
+}
+
+int upload_pair(orbhip_matcher* m, PairStage& ps, const OrbKeypoint* kp1, const uint8_t* desc1, int n1, const OrbKeypoint* kp2,
+                const uint8_t* desc2, int n2) {
+    const int32_t n[2] = {n1, n2};
+    HIPCHK(hipMemcpyAsync(ps.n, n, sizeof(n), hipMemcpyHostToDevice, m->stream));
+    if (n1) {
+        HIPCHK(hipMemcpyAsync(ps.kp1, kp1, sizeof(OrbKeypoint) * n1, hipMemcpyHostToDevice, m->stream));
+        HIPCHK(hipMemcpyAsync(ps.desc1, desc1, 32 * (size_t)n1, hipMemcpyHostToDevice, m->stream));
+    }
+    if (n2) {
+        HIPCHK(hipMemcpyAsync(ps.kp2, kp2, sizeof(OrbKeypoint) * n2, hipMemcpyHostToDevice, m->stream));
+        HIPCHK(hipMemcpyAsync(ps.desc2, desc2, 32 * (size_t)n2, hipMemcpyHostToDevice, m->stream));
+    }
+    HIPCHK(hipStreamSynchronize(m->stream));  // n[] lives on this stack frame
+    return ORBHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int orbhip_search_for_initialization(orbhip_matcher* m, const OrbKeypoint* kp1, const uint8_t* desc1, int n1,
+                                     const OrbKeypoint* kp2, const uint8_t* desc2, int n2, OrbFrameBounds bounds,
+                                     float* prev_matched, int window_size, float nnratio, int check_orientation,
+                                     int32_t* matches12, int32_t* nmatches) {
+    if (!m) return orb_fail(ORBHIP_EINVAL, "null matcher");
+    if (n1 < 0 || n2 < 0) return orb_fail(ORBHIP_EINVAL, "negative size");
+    if (!nmatches || (n1 && (!kp1 || !desc1 || !prev_matched || !matches12)) || (n2 && (!kp2 || !desc2)))
+        return orb_fail(ORBHIP_EINVAL, "null buffer");
+    const int cap = std::max(1, std::max(n1, n2));
+    int rc = check_frames(m, 1, cap, bounds);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(m->device));
+    PairStage ps;
+    if ((rc = stage_pair(m, cap, ps))) return rc;
+    if ((rc = upload_pair(m, ps, kp1, desc1, n1, kp2, desc2, n2))) return rc;
+    if (n1) HIPCHK(hipMemcpy(ps.prev, prev_matched, sizeof(float) * 2 * n1, hipMemcpyHostToDevice));
+    if ((rc = orbhip_frame_grid_device(m, ps.kp2, ps.n + 1, 1, cap, bounds, ps.cell_start, ps.cell_items))) return rc;
+    if ((rc = orbhip_search_for_initialization_device(m, ps.kp1, ps.desc1, ps.n, ps.kp2, ps.desc2, ps.n + 1, ps.cell_start,
+                                                      ps.cell_items, 1, cap, bounds, ps.prev, window_size, nnratio,
+                                                      check_orientation, ps.matches, ps.nmatches)))
+        return rc;
+    if (n1) {
+        HIPCHK(hipMemcpy(matches12, ps.matches, sizeof(int32_t) * n1, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(prev_matched, ps.prev, sizeof(float) * 2 * n1, hipMemcpyDeviceToHost));
+    }
+    HIPCHK(hipMemcpy(nmatches, ps.nmatches, sizeof(int32_t), hipMemcpyDeviceToHost));
+    return ORBHIP_OK;
+}
+
+int orbhip_window_search(orbhip_matcher* m, const OrbKeypoint* kp1, const uint8_t* desc1, int n1, const uint8_t* valid1,
+                         const OrbKeypoint* kp2, const uint8_t* desc2, int n2, OrbFrameBounds bounds, int window_size,
+                         int min_level, int max_level, float nnratio, int check_orientation, int32_t* matches21,
+                         int32_t* nmatches) {
+    if (!m) return orb_fail(ORBHIP_EINVAL, "null matcher");
+    if (n1 < 0 || n2 < 0) return orb_fail(ORBHIP_EINVAL, "negative size");
+    if (!nmatches || (n1 && (!kp1 || !desc1 || !valid1)) || (n2 && (!kp2 || !desc2 || !matches21)))
+        return orb_fail(ORBHIP_EINVAL, "null buffer");
+    const int cap = std::max(1, std::max(n1, n2));
+    int rc = check_frames(m, 1, cap, bounds);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(m->device));
+    PairStage ps;
+    if ((rc = stage_pair(m, cap, ps))) return rc;
+    if ((rc = upload_pair(m, ps, kp1, desc1, n1, kp2, desc2, n2))) return rc;
+    if (n1) HIPCHK(hipMemcpy(ps.valid1, valid1, n1, hipMemcpyHostToDevice));
+    if ((rc = orbhip_frame_grid_device(m, ps.kp2, ps.n + 1, 1, cap, bounds, ps.cell_start, ps.cell_items))) return rc;
+    if ((rc = orbhip_window_search_device(m, ps.kp1, ps.desc1, ps.n, ps.valid1, ps.kp2, ps.desc2, ps.n + 1, ps.cell_start,
+                                          ps.cell_items, 1, cap, bounds, window_size, min_level, max_level, nnratio,
+                                          check_orientation, ps.matches, ps.nmatches)))
+        return rc;
+    if (n2) HIPCHK(hipMemcpy(matches21, ps.matches, sizeof(int32_t) * n2, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(nmatches, ps.nmatches, sizeof(int32_t), hipMemcpyDeviceToHost));
+    return ORBHIP_OK;
+}
+
+}  // extern "C"

@@ -114,6 +114,40 @@ class ORBmatcher:
             int(self.mbCheckOrientation), m21.data_ptr(), nm.data_ptr()))
         return nm, m21
 
+    def search_for_initialization_host(self, kp1, desc1, kp2, desc2, bounds, prev_matched, windowSize=10):
+        """One frame pair from host arrays (what a forwarding ORBmatcher::SearchForInitialization does).
+        Returns (nmatches, vnMatches12, updated vbPrevMatched)."""
+        from .extractor import KP_DTYPE
+        kp1 = np.ascontiguousarray(kp1, dtype=KP_DTYPE)
+        kp2 = np.ascontiguousarray(kp2, dtype=KP_DTYPE)
+        desc1 = np.ascontiguousarray(desc1, dtype=np.uint8).reshape(-1, 32)
+        desc2 = np.ascontiguousarray(desc2, dtype=np.uint8).reshape(-1, 32)
+        prev = np.array(prev_matched, dtype=np.float32).reshape(-1, 2).copy()
+        m12 = np.full(max(len(kp1), 1), -1, np.int32)
+        nm = C.c_int32(0)
+        _lib.check(self._L.orbhip_search_for_initialization(
+            self._h, _p(kp1), _p(desc1), len(kp1), _p(kp2), _p(desc2), len(kp2), _lib.OrbFrameBounds(*map(int, bounds)),
+            _p(prev), int(windowSize), self.mfNNratio, int(self.mbCheckOrientation), _p(m12), C.byref(nm)))
+        return nm.value, m12[:len(kp1)].copy(), prev
+
+    def window_search_host(self, kp1, desc1, valid1, kp2, desc2, bounds, windowSize, minScaleLevel=-1,
+                           maxScaleLevel=INT_MAX):
+        """One frame pair from host arrays (what a forwarding ORBmatcher::WindowSearch does).
+        Returns (nmatches, vnMatches21)."""
+        from .extractor import KP_DTYPE
+        kp1 = np.ascontiguousarray(kp1, dtype=KP_DTYPE)
+        kp2 = np.ascontiguousarray(kp2, dtype=KP_DTYPE)
+        desc1 = np.ascontiguousarray(desc1, dtype=np.uint8).reshape(-1, 32)
+        desc2 = np.ascontiguousarray(desc2, dtype=np.uint8).reshape(-1, 32)
+        valid1 = np.ascontiguousarray(valid1, dtype=np.uint8)
+        m21 = np.full(max(len(kp2), 1), -1, np.int32)
+        nm = C.c_int32(0)
+        _lib.check(self._L.orbhip_window_search(
+            self._h, _p(kp1), _p(desc1), len(kp1), _p(valid1), _p(kp2), _p(desc2), len(kp2),
+            _lib.OrbFrameBounds(*map(int, bounds)), int(windowSize), int(minScaleLevel), int(maxScaleLevel),
+            self.mfNNratio, int(self.mbCheckOrientation), _p(m21), C.byref(nm)))
+        return nm.value, m21[:len(kp2)].copy()
+
     def valu_rate(self, mode):
         """Sustained lane-ops/s of v_bcnt (0), the xor+bcnt mix (1) or v_add (2) on this device."""
         return float(self._L.orbhip_valu_rate(self._h, mode))

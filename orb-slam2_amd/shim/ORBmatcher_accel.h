@@ -10,6 +10,10 @@
 #else
 #include <opencv2/core/core.hpp>
 #endif
+#include <climits>
+#include <stdexcept>
+#include <vector>
+
 #include "../../include/orbhip.h"
 
 namespace ORB_SLAM {
@@ -19,6 +23,67 @@ struct ORBmatcherAccel {
     static const int HISTO_LENGTH = 30;
     static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b) {
         return orbhip_hamming_distance(a.ptr<int32_t>(), b.ptr<int32_t>());
+    }
+
+    // The two windowed matchers, with the reference's signatures (include/ORBmatcher.h:71,76).  In the
+    // reference tree these bodies replace src/ORBmatcher.cc:420-527 and :609-724; FrameT is
+    // ORB_SLAM::Frame (members mvKeysUn, mDescriptors, mvpMapPoints and the static image bounds
+    // mnMinX..mnMaxY, include/Frame.h).  MapPointT needs isBad().
+    float mfNNratio;
+    bool mbCheckOrientation;
+    orbhip_matcher* handle;
+    explicit ORBmatcherAccel(float nnratio = 0.6, bool checkOri = true, int device = 0)
+        : mfNNratio(nnratio), mbCheckOrientation(checkOri), handle(0) {
+        if (orbhip_matcher_create(&handle, device) != ORBHIP_OK) throw std::runtime_error(orbhip_last_error());
+    }
+    ~ORBmatcherAccel() { orbhip_matcher_destroy(handle); }
+
+    template <class FrameT>
+    static std::vector<unsigned char> packDescriptors(const FrameT& F) {
+        std::vector<unsigned char> d((size_t)F.mDescriptors.rows * 32);
+        for (int i = 0; i < F.mDescriptors.rows; i++) {
+            const unsigned char* r = F.mDescriptors.template ptr<unsigned char>(i);
+            for (int b = 0; b < 32; b++) d[(size_t)i * 32 + b] = r[b];
+        }
+        return d;
+    }
+
+    template <class FrameT>
+    int SearchForInitialization(FrameT& F1, FrameT& F2, std::vector<cv::Point2f>& vbPrevMatched,
+                                std::vector<int>& vnMatches12, int windowSize = 10) {
+        static_assert(sizeof(cv::KeyPoint) == sizeof(OrbKeypoint), "cv::KeyPoint layout");
+        static_assert(sizeof(cv::Point2f) == 8, "cv::Point2f layout");
+        const int n1 = (int)F1.mvKeysUn.size(), n2 = (int)F2.mvKeysUn.size();
+        vnMatches12.assign(n1, -1);
+        const std::vector<unsigned char> d1 = packDescriptors(F1), d2 = packDescriptors(F2);
+        const OrbFrameBounds b = {FrameT::mnMinX, FrameT::mnMinY, FrameT::mnMaxX, FrameT::mnMaxY};
+        int nmatches = 0;
+        if (orbhip_search_for_initialization(handle, (const OrbKeypoint*)F1.mvKeysUn.data(), d1.data(), n1,
+                                             (const OrbKeypoint*)F2.mvKeysUn.data(), d2.data(), n2, b,
+                                             (float*)vbPrevMatched.data(), windowSize, mfNNratio, mbCheckOrientation,
+                                             vnMatches12.data(), &nmatches) != ORBHIP_OK)
+            throw std::runtime_error(orbhip_last_error());
+        return nmatches;
+    }
+
+    template <class FrameT, class MapPointT>
+    int WindowSearch(FrameT& F1, FrameT& F2, int windowSize, std::vector<MapPointT*>& vpMapPointMatches2,
+                     int minScaleLevel = -1, int maxScaleLevel = INT_MAX) {
+        const int n1 = (int)F1.mvpMapPoints.size(), n2 = (int)F2.mvKeysUn.size();
+        vpMapPointMatches2.assign(F2.mvpMapPoints.size(), static_cast<MapPointT*>(0));
+        std::vector<unsigned char> valid(n1 ? n1 : 1);
+        for (int i = 0; i < n1; i++) valid[i] = F1.mvpMapPoints[i] && !F1.mvpMapPoints[i]->isBad();
+        const std::vector<unsigned char> d1 = packDescriptors(F1), d2 = packDescriptors(F2);
+        const OrbFrameBounds b = {FrameT::mnMinX, FrameT::mnMinY, FrameT::mnMaxX, FrameT::mnMaxY};
+        std::vector<int> vnMatches21(n2 ? n2 : 1, -1);
+        int nmatches = 0;
+        if (orbhip_window_search(handle, (const OrbKeypoint*)F1.mvKeysUn.data(), d1.data(), n1, valid.data(),
+                                 (const OrbKeypoint*)F2.mvKeysUn.data(), d2.data(), n2, b, windowSize, minScaleLevel,
+                                 maxScaleLevel, mfNNratio, mbCheckOrientation, vnMatches21.data(), &nmatches) != ORBHIP_OK)
+            throw std::runtime_error(orbhip_last_error());
+        for (int i2 = 0; i2 < n2; i2++)
+            if (vnMatches21[i2] >= 0) vpMapPointMatches2[i2] = F1.mvpMapPoints[vnMatches21[i2]];
+        return nmatches;
     }
 };
 }  // namespace ORB_SLAM

@@ -9,6 +9,20 @@
 #include "ORBextractor.h"
 #include "ORBmatcher_accel.h"
 
+// Stand-ins with the members of ORB_SLAM::Frame / MapPoint the forwarding matchers touch.
+struct FakeMapPoint {
+    bool bad;
+    FakeMapPoint() : bad(false) {}
+    bool isBad() const { return bad; }
+};
+struct FakeFrame {
+    std::vector<cv::KeyPoint> mvKeysUn;
+    cv::Mat mDescriptors;
+    std::vector<FakeMapPoint*> mvpMapPoints;
+    static int mnMinX, mnMinY, mnMaxX, mnMaxY;
+};
+int FakeFrame::mnMinX, FakeFrame::mnMinY, FakeFrame::mnMaxX, FakeFrame::mnMaxY;
+
 int main(int argc, char** argv) {
     if (argc < 6) return 2;
     const int rows = atoi(argv[2]), cols = atoi(argv[3]), nf = atoi(argv[4]);
@@ -35,6 +49,40 @@ int main(int argc, char** argv) {
     fwrite(&dist01, 4, 1, f);
     if (n) fwrite(&keys[0], sizeof(cv::KeyPoint), n, f);
     for (int i = 0; i < n; i++) fwrite(descriptors.ptr<unsigned char>(i), 1, 32, f);
+    // the windowed matchers through their forwarding bodies: frame 2 is the image shifted by (5, 3)
+    std::vector<unsigned char> buf2(buf.size());
+    for (int y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++) buf2[(size_t)y * cols + x] = buf[(size_t)((y + rows - 3) % rows) * cols + (x + cols - 5) % cols];
+    cv::Mat im2(rows, cols, CV_8U, buf2.data(), (size_t)cols);
+    FakeFrame F1, F2;
+    FakeFrame::mnMinX = 0; FakeFrame::mnMinY = 0; FakeFrame::mnMaxX = cols; FakeFrame::mnMaxY = rows;
+    F1.mvKeysUn = keys;
+    F1.mDescriptors = descriptors;
+    extractor(im2, cv::Mat(), F2.mvKeysUn, F2.mDescriptors);
+    static FakeMapPoint good, bad;
+    bad.bad = true;
+    F1.mvpMapPoints.resize(F1.mvKeysUn.size());
+    for (size_t i = 0; i < F1.mvpMapPoints.size(); i++) F1.mvpMapPoints[i] = i % 7 == 0 ? (FakeMapPoint*)0 : (i % 11 == 0 ? &bad : &good);
+    F2.mvpMapPoints.assign(F2.mvKeysUn.size(), (FakeMapPoint*)0);
+    ORB_SLAM::ORBmatcherAccel matcher(0.9f, true);
+    std::vector<cv::Point2f> prev(F1.mvKeysUn.size());
+    for (size_t i = 0; i < prev.size(); i++) prev[i] = F1.mvKeysUn[i].pt;
+    std::vector<int> m12;
+    int nInit = matcher.SearchForInitialization(F1, F2, prev, m12, 100);
+    std::vector<FakeMapPoint*> mp2;
+    int nWin = matcher.WindowSearch(F1, F2, 50, mp2, 0);
+    int n2 = (int)F2.mvKeysUn.size();
+    fwrite(&n2, 4, 1, f);
+    if (n2) fwrite(&F2.mvKeysUn[0], sizeof(cv::KeyPoint), n2, f);
+    for (int i = 0; i < n2; i++) fwrite(F2.mDescriptors.ptr<unsigned char>(i), 1, 32, f);
+    fwrite(&nInit, 4, 1, f);
+    if (n) fwrite(&m12[0], 4, n, f);
+    if (n) fwrite(&prev[0], 8, n, f);
+    fwrite(&nWin, 4, 1, f);
+    for (int i = 0; i < n2; i++) {
+        int has = mp2[i] != 0;
+        fwrite(&has, 4, 1, f);
+    }
     fclose(f);
     return 0;
 }

@@ -21,10 +21,43 @@ def test_cpp_shim_matches_oracle(orb, orbref, synth, tmp_path):
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     blob = out.read_bytes()
     n, dist01 = np.frombuffer(blob[:8], np.int32)
-    kp = np.frombuffer(blob[8:8 + 28 * n], orb.KP_DTYPE)
-    desc = np.frombuffer(blob[8 + 28 * n:], np.uint8).reshape(n, 32)
+    o = 8
+    kp = np.frombuffer(blob[o:o + 28 * n], orb.KP_DTYPE)
+    o += 28 * n
+    desc = np.frombuffer(blob[o:o + 32 * n], np.uint8).reshape(n, 32)
+    o += 32 * n
     rkp, rdesc = orbref.RefExtractor(1000, 1.2, 8, 1, 20)(img)
     assert n == len(rkp)
     assert np.array_equal(kp.view(np.uint32), rkp.view(np.uint32))
     assert np.array_equal(desc, rdesc)
     assert dist01 == orbref.hamming(rdesc[0], rdesc[1])
+
+    # second frame + the forwarding SearchForInitialization / WindowSearch bodies (shim/ORBmatcher_accel.h)
+    n2 = int(np.frombuffer(blob[o:o + 4], np.int32)[0])
+    o += 4
+    kp2 = np.frombuffer(blob[o:o + 28 * n2], orb.KP_DTYPE)
+    o += 28 * n2
+    desc2 = np.frombuffer(blob[o:o + 32 * n2], np.uint8).reshape(n2, 32)
+    o += 32 * n2
+    n_init = int(np.frombuffer(blob[o:o + 4], np.int32)[0])
+    o += 4
+    m12 = np.frombuffer(blob[o:o + 4 * n], np.int32)
+    o += 4 * n
+    prev = np.frombuffer(blob[o:o + 8 * n], np.float32).reshape(n, 2)
+    o += 8 * n
+    n_win = int(np.frombuffer(blob[o:o + 4], np.int32)[0])
+    o += 4
+    has2 = np.frombuffer(blob[o:o + 4 * n2], np.int32)
+    img2 = np.roll(img, (3, 5), axis=(0, 1))
+    rkp2, rdesc2 = orbref.RefExtractor(1000, 1.2, 8, 1, 20)(img2)
+    assert np.array_equal(kp2.view(np.uint32), rkp2.view(np.uint32)) and np.array_equal(desc2, rdesc2)
+    bounds = [0, 0, 640, 480]
+    prev0 = np.stack([rkp["x"], rkp["y"]], 1)
+    rn, r12, rprev = orbref.search_for_initialization(rkp, rdesc, rkp2, rdesc2, bounds, prev0, 100, np.float32(0.9), True)
+    assert n_init == rn and rn > 20
+    assert np.array_equal(m12, r12) and np.array_equal(prev.view(np.uint32), rprev.view(np.uint32))
+    idx = np.arange(n)
+    valid = ((idx % 7 != 0) & (idx % 11 != 0)).astype(np.uint8)
+    rn, r21 = orbref.window_search(rkp, rdesc, valid, rkp2, rdesc2, bounds, 50, 0, 2**31 - 1, np.float32(0.9), True)
+    assert n_win == rn and rn > 20
+    assert np.array_equal(has2 != 0, r21 >= 0)

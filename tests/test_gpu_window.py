@@ -228,3 +228,22 @@ def test_window_search_on_extracted_frames(orb, orbref, synth):
     assert _run_window(orb, orbref, pairs, valids, [0, 0, w, h], 30, -1, INT_MAX, 0.8, True) > 200
     m = orb.ORBmatcher(0.9, True)
     assert _run_search_init(orb, orbref, m, pairs, [0, 0, w, h], 100, 0.9, True, cap=_pad_equal(pairs)) > 50
+
+
+def test_host_pointer_forms(orb, orbref):
+    """The single-pair host forms (copy in, grid, match, copy out) give the oracle's answers."""
+    w, h = 752, 480
+    fr, rng = frames_for(orbref, 41, [1200, 0, 3], w, h, levels=3, ties=True, cluster=True)
+    bounds = [0, 0, w, h]
+    for kp, de in fr:
+        kp2, de2 = moved(orbref, rng, kp, de, w, h, rot=45.0)
+        m = orb.ORBmatcher(0.9, True)
+        prev = np.stack([kp["x"], kp["y"]], 1).astype(np.float32).reshape(-1, 2)
+        n, m12, pv = m.search_for_initialization_host(kp, de, kp2, de2, bounds, prev, 100)
+        rn, r12, rpv = orbref.search_for_initialization(kp, de, kp2, de2, bounds, prev, 100, m.mfNNratio, True)
+        assert n == rn and np.array_equal(m12, r12) and np.array_equal(pv.view(np.uint32), rpv.view(np.uint32))
+        m = orb.ORBmatcher(0.6, True)
+        valid = (rng.random(len(kp)) < 0.8).astype(np.uint8)
+        n, m21 = m.window_search_host(kp, de, valid, kp2, de2, bounds, 100, 0)
+        rn, r21 = orbref.window_search(kp, de, valid, kp2, de2, bounds, 100, 0, INT_MAX, m.mfNNratio, True)
+        assert n == rn and np.array_equal(m21, r21)
