@@ -233,6 +233,16 @@ int orbhip_window_search(orbhip_matcher* m, const OrbKeypoint* kp1, const uint8_
                          int min_level, int max_level, float nnratio, int check_orientation, int32_t* matches21,
                          int32_t* nmatches);
 
+/* Replaces the descriptor choice of MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:221-250)
+ * for npoints map points at once: point p observes the descriptors (rows of 32 bytes)
+ * d_desc[32*d_start[p] ... 32*d_start[p+1]); d_best_idx[p] = the row (relative to d_start[p]) with
+ * the least median Hamming distance to all rows of the point, the first one on ties;
+ * d_best_median[p] = that median (the element of rank (size_t)(0.5*(N-1)) of the sorted row).  A
+ * point without observations gives -1 / INT_MAX.  Points with more than 128 observations make the
+ * next orbhip_matcher_synchronize fail with ORBHIP_ECAP.  Device pointers; asynchronous. */
+int orbhip_distinctive_descriptors_device(orbhip_matcher* m, const uint8_t* d_desc, const int32_t* d_start,
+                                          int npoints, int32_t* d_best_idx, int32_t* d_best_median);
+
 /* Device self-tests of the arithmetic helpers (test instrumentation, host pointers, blocking):
  * which 0: n (y, x) float pairs -> n floats, the device's fastAtan2 in degrees
  *       1: n float angles (radians) -> n (cos, sin) float pairs as the descriptor kernel computes them

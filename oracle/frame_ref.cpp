@@ -8,11 +8,14 @@
 //   GetFeaturesInArea     src/Frame.cc:201-266
 //   WindowSearch          src/ORBmatcher.cc:420-527
 //   SearchForInitialization  src/ORBmatcher.cc:609-724
+// and of the descriptor choice of a map point:
+//   MapPoint::ComputeDistinctiveDescriptors  src/MapPoint.cc:191-256
 // Arithmetic follows the reference expression by expression in fp32 (this file is compiled with
 // -ffp-contract=off).  Unqualified floor/ceil/round/abs in src/Frame.cc resolve to the float
 // overloads of namespace std (pulled in through Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h).
 #include "orb_ref.h"
 
+#include <algorithm>
 #include <climits>
 #include <cmath>
 #include <cstring>
@@ -268,6 +271,35 @@ int orbref_window_search(const void* kp1, const uint8_t* desc1, int n1, const ui
         }
     }
     return nmatches;
+}
+
+// src/MapPoint.cc:221-250 for one map point with N observed descriptors (rows of 32 bytes):
+// returns BestIdx, *best_median = BestMedian.  N == 0 returns -1 (the reference returns early).
+int orbref_distinctive_descriptor(const uint8_t* desc, int N, int32_t* best_median) {
+    if (best_median) *best_median = INT_MAX;
+    if (N <= 0) return -1;
+    std::vector<float> Distances((size_t)N * N);
+    for (size_t i = 0; i < (size_t)N; i++) {
+        Distances[i * N + i] = 0;
+        for (size_t j = i + 1; j < (size_t)N; j++) {
+            int distij = orbref_hamming(desc + i * 32, desc + j * 32);
+            Distances[i * N + j] = distij;
+            Distances[j * N + i] = distij;
+        }
+    }
+    int BestMedian = INT_MAX;
+    int BestIdx = 0;
+    for (size_t i = 0; i < (size_t)N; i++) {
+        std::vector<int> vDists(Distances.begin() + i * N, Distances.begin() + (i + 1) * N);
+        std::sort(vDists.begin(), vDists.end());
+        int median = vDists[0.5 * (N - 1)];
+        if (median < BestMedian) {
+            BestMedian = median;
+            BestIdx = (int)i;
+        }
+    }
+    if (best_median) *best_median = BestMedian;
+    return BestIdx;
 }
 
 }  // extern "C"

@@ -118,6 +118,9 @@ int orbref_search_for_initialization(const void* kp1, const uint8_t* desc1, int 
 int orbref_window_search(const void* kp1, const uint8_t* desc1, int n1, const uint8_t* valid1, const void* kp2,
                          const uint8_t* desc2, int n2, const int32_t bounds[4], int window_size, int min_level,
                          int max_level, float nnratio, int check_orientation, int32_t* matches21);
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:221-250): index of the descriptor with the
+ * least median distance to the others (first one on ties), its median in *best_median. */
+int orbref_distinctive_descriptor(const uint8_t* desc, int n, int32_t* best_median);
 
 #ifdef __cplusplus
 }

@@ -74,6 +74,7 @@ def lib():
         L.orbref_frame_grid.argtypes = [vp, i32, vp, vp, vp]
         L.orbref_features_in_area.argtypes = [vp, i32, vp, f32, f32, f32, i32, i32, vp, i32]
         L.orbref_search_for_initialization.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, i32, f32, i32, vp]
+        L.orbref_distinctive_descriptor.argtypes = [vp, i32, vp]
         L.orbref_window_search.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, f32, i32, vp]
         _lib = L
     return _lib
@@ -234,3 +235,11 @@ def window_search(kp1, desc1, valid1, kp2, desc2, bounds, window_size, min_level
     n = lib().orbref_window_search(_p(kp1), _p(desc1), len(kp1), _p(valid1), _p(kp2), _p(desc2), len(kp2), _p(b),
                                    window_size, min_level, max_level, nnratio, int(check_orientation), _p(m21))
     return n, m21[:len(kp2)].copy()
+
+
+def distinctive_descriptor(desc):
+    """MapPoint::ComputeDistinctiveDescriptors on one set of observations: (BestIdx, BestMedian)."""
+    desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 32)
+    med = C.c_int32(0)
+    idx = lib().orbref_distinctive_descriptor(_p(desc), len(desc), C.byref(med))
+    return idx, med.value

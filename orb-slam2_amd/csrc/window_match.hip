@@ -839,3 +839,84 @@ int orbhip_window_search(orbhip_matcher* m, const OrbKeypoint* kp1, const uint8_
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:221-250), one wave per map point.
+// The N x N distance matrix lives in LDS (u16); lane i then finds the median of row i — the
+// element of rank (size_t)(0.5 * (N - 1)) — by bisection on the value (distances are 0..256), and
+// the wave takes the first row attaining the smallest median.
+namespace {
+
+#define DD_MAX_N 128
+
+__global__ __launch_bounds__(64) void k_distinctive(const uint8_t* __restrict__ desc, const int32_t* __restrict__ start,
+                                                    int npoints, int32_t* __restrict__ best_idx,
+                                                    int32_t* __restrict__ best_median, int* __restrict__ err) {
+    __shared__ uint16_t dist[DD_MAX_N * DD_MAX_N];
+    __shared__ uint32_t rows[DD_MAX_N * 8];
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int s0 = start[p];
+    int N = start[p + 1] - s0;
+    if (N <= 0) {
+        if (lane == 0) {
+            best_idx[p] = -1;
+            best_median[p] = INT_MAX;
+        }
+        return;
+    }
+    if (N > DD_MAX_N) {  // not representable in the LDS matrix: flagged, nothing is written
+        if (lane == 0) {
+            atomicOr(err, 8);
+            best_idx[p] = -1;
+            best_median[p] = INT_MAX;
+        }
+        return;
+    }
+    const uint32_t* src = (const uint32_t*)(desc + (long long)s0 * 32);
+    for (int i = lane; i < N * 8; i += 64) rows[i] = src[i];
+    wave_fence();
+    for (int e = lane; e < N * N; e += 64) {
+        const int i = e / N, j = e - i * N;
+        int d = 0;
+#pragma unroll
+        for (int w = 0; w < 8; w++) d += __popc(rows[i * 8 + w] ^ rows[j * 8 + w]);
+        dist[e] = (uint16_t)d;
+    }
+    wave_fence();
+    const int rank = (int)(0.5 * (N - 1));
+    unsigned long long bestkey = KEY_NONE;
+    for (int i = lane; i < N; i += 64) {
+        // smallest v with #{j : dist[i][j] <= v} > rank
+        int lo = 0, hi = 256;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            int c = 0;
+            for (int j = 0; j < N; j++) c += dist[i * N + j] <= mid;
+            if (c > rank) hi = mid;
+            else lo = mid + 1;
+        }
+        bestkey = min(bestkey, ((unsigned long long)lo << 32) | (unsigned)i);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bestkey = min(bestkey, __shfl_xor(bestkey, o));
+    if (lane == 0) {
+        best_idx[p] = (int32_t)(bestkey & 0xffffffffu);
+        best_median[p] = (int32_t)(bestkey >> 32);
+    }
+}
+
+}  // namespace
+
+extern "C" int orbhip_distinctive_descriptors_device(orbhip_matcher* m, const uint8_t* d_desc, const int32_t* d_start,
+                                                     int npoints, int32_t* d_best_idx, int32_t* d_best_median) {
+    if (!m) return orb_fail(ORBHIP_EINVAL, "null matcher");
+    if (npoints < 0) return orb_fail(ORBHIP_EINVAL, "negative size");
+    if (npoints == 0) return ORBHIP_OK;
+    if (!d_desc || !d_start || !d_best_idx || !d_best_median) return orb_fail(ORBHIP_EINVAL, "null buffer");
+    HIPCHK(hipSetDevice(m->device));
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_distinctive, dim3(npoints), dim3(64), 0, m->stream, d_desc, d_start, npoints, d_best_idx,
+                       d_best_median, m->d_err);
+    HIPCHK(hipGetLastError());
+    return ORBHIP_OK;
+}

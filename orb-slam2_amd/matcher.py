@@ -148,6 +148,21 @@ class ORBmatcher:
             self.mfNNratio, int(self.mbCheckOrientation), _p(m21), C.byref(nm)))
         return nm.value, m21[:len(kp2)].copy()
 
+    def ComputeDistinctiveDescriptors(self, desc, start):
+        """MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:191-256) for many map points:
+        desc [total, 32] u8 and start [npoints + 1] i32 CUDA tensors (observations of point p are rows
+        start[p]..start[p+1]).  Returns (BestIdx, BestMedian) int32 CUDA tensors of length npoints."""
+        import torch
+        assert desc.is_cuda and start.is_cuda and start.dtype == torch.int32
+        npts = int(start.numel()) - 1
+        idx = torch.empty(max(npts, 1), dtype=torch.int32, device=start.device)
+        med = torch.empty(max(npts, 1), dtype=torch.int32, device=start.device)
+        torch.cuda.synchronize()
+        _lib.check(self._L.orbhip_distinctive_descriptors_device(self._h, desc.data_ptr(), start.data_ptr(), npts,
+                                                                 idx.data_ptr(), med.data_ptr()))
+        self.synchronize()
+        return idx[:npts], med[:npts]
+
     def valu_rate(self, mode):
         """Sustained lane-ops/s of v_bcnt (0), the xor+bcnt mix (1) or v_add (2) on this device."""
         return float(self._L.orbhip_valu_rate(self._h, mode))

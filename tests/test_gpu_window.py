@@ -247,3 +247,32 @@ def test_host_pointer_forms(orb, orbref):
         n, m21 = m.window_search_host(kp, de, valid, kp2, de2, bounds, 100, 0)
         rn, r21 = orbref.window_search(kp, de, valid, kp2, de2, bounds, 100, 0, INT_MAX, m.mfNNratio, True)
         assert n == rn and np.array_equal(m21, r21)
+
+
+def test_distinctive_descriptors(orb, orbref):
+    """MapPoint::ComputeDistinctiveDescriptors, many map points at once: BestIdx and BestMedian."""
+    import torch
+    rng = np.random.default_rng(51)
+    sizes = [0, 1, 2, 3, 4, 5, 7, 8, 33, 64, 65, 100, 128] + list(rng.integers(1, 40, 300))
+    descs, start = [], [0]
+    for n in sizes:
+        base = rng.integers(0, 256, (1, 32), dtype=np.uint8)
+        d = np.repeat(base, n, axis=0)
+        for i in range(n):  # observations of one point: a common descriptor with a few flipped bits (ties abound)
+            for _ in range(rng.integers(0, 12)):
+                d[i, rng.integers(0, 32)] ^= np.uint8(1 << rng.integers(0, 8))
+        if n >= 3 and rng.random() < 0.3:
+            d[rng.integers(0, n)] = ~base[0]  # an outlier at distance ~256
+        descs.append(d)
+        start.append(start[-1] + n)
+    alld = np.concatenate(descs, 0)
+    m = orb.ORBmatcher()
+    idx, med = m.ComputeDistinctiveDescriptors(torch.from_numpy(alld).cuda(), torch.tensor(start, dtype=torch.int32).cuda())
+    idx, med = idx.cpu().numpy(), med.cpu().numpy()
+    for p, d in enumerate(descs):
+        ri, rm = orbref.distinctive_descriptor(d)
+        assert (idx[p], med[p]) == (ri, rm), "point %d (N = %d)" % (p, len(d))
+    # more observations than the LDS matrix holds are reported, not silently truncated
+    big = rng.integers(0, 256, (129, 32), dtype=np.uint8)
+    with pytest.raises(orb.OrbhipError):
+        m.ComputeDistinctiveDescriptors(torch.from_numpy(big).cuda(), torch.tensor([0, 129], dtype=torch.int32).cuda())

@@ -124,3 +124,15 @@ def test_rotation_histogram_drops_the_outlier_bin(orbref):
     assert nm == 12 and m21[12] == -1
     # negative difference wraps: 10 - 100 + 360 = 270 -> bin 9
     assert orbref.lib().orbref_rot_bin(10.0, 100.0) == 9
+
+
+def test_distinctive_descriptor_median_rank_and_first_minimum(orbref):
+    # N = 4: rank (size_t)(0.5 * 3) = 1 of the sorted row (which contains the 0 of the diagonal)
+    # rows: a = 0 bits, b = 2 bits, c = 4 bits (supersets), d = 40 bits
+    d = np.stack([bits(0), bits(2), bits(4), bits(40)])
+    # row a: [0,2,4,40] -> 2; row b: [0,2,2,38] -> 2; row c: [0,2,4,36] -> 2; row d: [0,36,38,40] -> 36
+    assert orbref.distinctive_descriptor(d) == (0, 2)  # first of the tied rows
+    assert orbref.distinctive_descriptor(d[::-1]) == (1, 2)
+    assert orbref.distinctive_descriptor(d[:1]) == (0, 0)
+    assert orbref.distinctive_descriptor(d[:2]) == (0, 0)  # N = 2: rank 0 is the diagonal
+    assert orbref.distinctive_descriptor(d[:0]) == (-1, INT_MAX)
