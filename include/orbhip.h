@@ -95,6 +95,7 @@ void* orbhip_extractor_stream(orbhip_extractor* e);
  *        4 = per-cell nToRetain of the level -> int32[nCells]
  *        5 = level keypoints after selection -> int32 triples x, y, score; returns count
  *        6 = per-cell candidates, cell-major raster order -> int32 triples x, y (cell coords), score
+ *        (score: the FAST score; with HARRIS_SCORE the IEEE bits of the float response)
  * Returns the number of bytes (stages 0-2) or elements written, or < 0. */
 int orbhip_debug_get(orbhip_extractor* e, int stage, int frame, int level, void* buf, size_t buf_bytes);
 /* Level geometry of the current image size: out[0]=w, [1]=h, [2]=levelCols, [3]=levelRows,

@@ -408,6 +408,14 @@ void harris_responses(const unsigned char* img, ptrdiff_t step, std::vector<KeyP
     }
 }
 
+// Third value of the stage taps: the FAST score as an integer, or the IEEE bits of the float Harris response.
+inline int tap_response(int scoreType, float r) {
+    if (scoreType != 0) return (int)r;
+    int bits;
+    memcpy(&bits, &r, sizeof bits);
+    return bits;
+}
+
 struct LevelTap {
     int w, h;
     int cols, rows, cellW, cellH, nfeaturesCell;
@@ -597,7 +605,7 @@ int orbref_extract(orbref_extractor* e, const uint8_t* img, int rows, int cols, 
                 for (size_t k = 0; k < cellKeyPoints[i][j].size(); k++) {
                     L.cand_xyr.push_back((int)cellKeyPoints[i][j][k].x);
                     L.cand_xyr.push_back((int)cellKeyPoints[i][j][k].y);
-                    L.cand_xyr.push_back((int)cellKeyPoints[i][j][k].response);
+                    L.cand_xyr.push_back(tap_response(e->scoreType, cellKeyPoints[i][j][k].response));
                 }
             }
 
@@ -646,7 +654,7 @@ int orbref_extract(orbref_extractor* e, const uint8_t* img, int rows, int cols, 
         for (size_t k = 0; k < keypoints.size(); k++) {
             L.kp_xyr.push_back((int)keypoints[k].x);
             L.kp_xyr.push_back((int)keypoints[k].y);
-            L.kp_xyr.push_back((int)keypoints[k].response);
+            L.kp_xyr.push_back(tap_response(e->scoreType, keypoints[k].response));
         }
     }
     // orientations (:705-706) on the unblurred pyramid

@@ -55,7 +55,8 @@ int orbref_extract(orbref_extractor* e, const uint8_t* img, int rows, int cols, 
 /* Stage taps, valid after orbref_extract.  Planes are (w+32) x (h+32) bytes, tightly packed. */
 int orbref_level_size(const orbref_extractor* e, int level, int* w, int* h);
 int orbref_plane(const orbref_extractor* e, int level, int blurred, uint8_t* out);
-/* Per-level keypoints after retainBest, before orientation/scaling: x, y (level coords), response. */
+/* Per-level keypoints after retainBest, before orientation/scaling: x, y (level coords), response
+ * (the FAST score as an integer; with HARRIS_SCORE the IEEE bits of the float response). */
 int orbref_level_keypoints(const orbref_extractor* e, int level, int32_t* xyr, int cap);
 /* Grid of the level: out[0]=levelCols, [1]=levelRows, [2]=cellW, [3]=cellH, [4]=nfeaturesCell. */
 int orbref_level_grid(const orbref_extractor* e, int level, int32_t* out);

@@ -28,10 +28,15 @@ void launch_select(hipStream_t st, const GeomDev& hg, int batch, const GeomDev* 
 void launch_blur(hipStream_t st, const GeomDev& hg, int batch, int level, const uint8_t* pyr, uint8_t* blur,
                  const GeomDev* dg, const int taps[7]);
 // IC_Angle + computeOrbDescriptor + output records, one half-wave per keypoint.
+// lvl_list holds key_words (1 or 2) 32-bit words per keypoint, low word first.
 void launch_orient_describe(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* pyr, const uint8_t* blur,
-                            const GeomDev* dg, const uint32_t* lvl_list, const int* lvl_count, const uint32_t* otab,
-                            float* angles, const int8_t* pattern, OrbKeypointDev* kp_out, uint8_t* desc_out, int* n_out,
-                            int cap);
+                            const GeomDev* dg, const uint32_t* lvl_list, int key_words, const int* lvl_count,
+                            const uint32_t* otab, float* angles, const int8_t* pattern, OrbKeypointDev* kp_out,
+                            uint8_t* desc_out, int* n_out, int cap);
+// HARRIS_SCORE: Harris responses of the FAST candidates into 64-bit keys, then the selection on those.
+void launch_harris_select(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* pyr, const GeomDev* dg,
+                          const CellDesc* cells, const uint32_t* cand, uint64_t* cand64, const int* n_total, int* n_retain,
+                          uint64_t* lvl_list64, int* lvl_count, int* err);
 void launch_test_atan2(hipStream_t st, const float* yx, float* out, int n);
 void launch_test_sincos(hipStream_t st, const float* in, float* out, int n);
 void launch_test_select(hipStream_t st, uint32_t* keys, int n, int nth);

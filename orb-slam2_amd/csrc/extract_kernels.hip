@@ -354,6 +354,75 @@ __global__ __launch_bounds__(256) void k_nms(const uint8_t* __restrict__ score, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// HarrisResponses(cellImage, keypoints, 7, HARRIS_K) (src/ORBextractor.cc:79-120,616-620): replaces
+// the FAST score of every candidate by the Harris measure of the 7 x 7 block around it.  One lane
+// per candidate reads the 9 x 9 window once (rows of three unaligned dwords) and evaluates the
+// reference's expression operation by operation in fp32.  The response goes into bits 63..32 of a
+// 64-bit key as an unsigned integer with the same order as the float; the 32-bit key stays below.
+__device__ __forceinline__ uint32_t float_to_ordered(float f) {
+    if (f == 0.f) f = 0.f;  // -0 and +0 compare equal as floats
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_to_float(uint32_t u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+__global__ __launch_bounds__(256) void k_harris(const uint8_t* __restrict__ pyr, const GeomDev* __restrict__ g,
+                                                const CellDesc* __restrict__ cells, const uint32_t* __restrict__ cand,
+                                                const int* __restrict__ n_total, uint64_t* __restrict__ cand64) {
+    const int c = blockIdx.x, f = blockIdx.y;
+    const CellDesc cd = cells[c];
+    const int n = min(n_total[(long long)f * g->cells_per_frame + c], cd.cand_cap);
+    const LevelGeom& L = g->lv[cd.level];
+    const int stride = L.stride;
+    const uint8_t* plane = pyr + (long long)f * g->frame_bytes + L.plane_off;
+    const uint32_t* src = cand + (long long)f * g->cand_per_frame + cd.cand_off;
+    uint64_t* dst = cand64 + (long long)f * g->cand_per_frame + cd.cand_off;
+    float scale = (1 << 2) * 7 * 255.0f;
+    scale = 1.0f / scale;
+    const float scale_sq_sq = __fmul_rn(__fmul_rn(__fmul_rn(scale, scale), scale), scale);
+    const float harris_k = 0.04f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const uint32_t key = src[i];
+        const int x = key & 0xfff, y = (key >> 12) & 0xfff;  // cell-image coordinates
+        // window rows y-4 .. y+4, columns x-4 .. x+4 in padded-plane coordinates
+        const uint8_t* w0 = plane + (long long)(ORB_EDGE + cd.ini_y + y - 4) * stride + (ORB_EDGE + cd.ini_x + x - 4);
+        int px[9][9];
+#pragma unroll
+        for (int r = 0; r < 9; r++) {
+            const uint8_t* row = w0 + (long long)r * stride;
+            const uint32_t d0 = *(const u32_unaligned*)row, d1 = *(const u32_unaligned*)(row + 4);
+            const uint32_t d2 = row[8];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                px[r][k] = (d0 >> (8 * k)) & 0xff;
+                px[r][4 + k] = (d1 >> (8 * k)) & 0xff;
+            }
+            px[r][8] = d2;
+        }
+        int a = 0, b = 0, cc = 0;
+#pragma unroll
+        for (int r = 1; r < 8; r++)
+#pragma unroll
+            for (int k = 1; k < 8; k++) {
+                const int Ix = (px[r][k + 1] - px[r][k - 1]) * 2 + (px[r - 1][k + 1] - px[r - 1][k - 1]) +
+                               (px[r + 1][k + 1] - px[r + 1][k - 1]);
+                const int Iy = (px[r + 1][k] - px[r - 1][k]) * 2 + (px[r + 1][k - 1] - px[r - 1][k - 1]) +
+                               (px[r + 1][k + 1] - px[r - 1][k + 1]);
+                a += Ix * Ix;
+                b += Iy * Iy;
+                cc += Ix * Iy;
+            }
+        const float fa = (float)a, fb = (float)b, fc = (float)cc;
+        const float sum = __fadd_rn(fa, fb);
+        const float resp = __fmul_rn(
+            __fsub_rn(__fsub_rn(__fmul_rn(fa, fb), __fmul_rn(fc, fc)), __fmul_rn(__fmul_rn(harris_k, sum), sum)), scale_sq_sq);
+        dst[i] = ((uint64_t)float_to_ordered(resp) << 32) | key;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Quota redistribution (src/ORBextractor.cc:622-670), per-cell retainBest (:683-685), cell-major
 // concatenation in level coordinates (:687-694) and per-level retainBest (:697-701), as three
 // kernels so that the per-cell selections (the bulk of the work, one wave each) spread over the
@@ -438,10 +507,11 @@ __global__ __launch_bounds__(256) void k_quota(const GeomDev* __restrict__ g, co
     for (int c = tid; c < nCells; c += 256) ret[c] = lret[c];
 }
 
+template <class KeyT>
 __global__ __launch_bounds__(256) void k_cell_select(const GeomDev* __restrict__ g, const CellDesc* __restrict__ cells,
-                                                     uint32_t* __restrict__ cand, const int* __restrict__ n_total,
+                                                     KeyT* __restrict__ cand, const int* __restrict__ n_total,
                                                      const int* __restrict__ n_retain) {
-    __shared__ uint32_t buf[4 * SEL_WCAP];
+    __shared__ KeyT buf[4 * SEL_WCAP];
     __shared__ uint16_t lists[4 * 2 * SEL_WCAP];
     int bx = blockIdx.x, f = blockIdx.y;
     xcd_frame_swizzle(bx, f, (int)gridDim.x, (int)gridDim.y);
@@ -451,9 +521,9 @@ __global__ __launch_bounds__(256) void k_cell_select(const GeomDev* __restrict__
     const long long fc = (long long)f * g->cells_per_frame + c;
     const int n = n_total[fc], kk = n_retain[fc];
     if (!(n > kk && kk > 0)) return;
-    uint32_t* list = cand + (long long)f * g->cand_per_frame + cells[c].cand_off;
+    KeyT* list = cand + (long long)f * g->cand_per_frame + cells[c].cand_off;
     if (n <= SEL_WCAP) {
-        uint32_t* wbuf = buf + wave * SEL_WCAP;
+        KeyT* wbuf = buf + wave * SEL_WCAP;
         uint16_t* wl = lists + wave * 2 * SEL_WCAP;
         for (int i = lane; i < n; i += 64) wbuf[i] = list[i];
         orbsel::wave_lds_fence();
@@ -465,11 +535,12 @@ __global__ __launch_bounds__(256) void k_cell_select(const GeomDev* __restrict__
     }
 }
 
+template <class KeyT>
 __global__ __launch_bounds__(256) void k_level_select(const GeomDev* __restrict__ g, const CellDesc* __restrict__ cells,
-                                                      const uint32_t* __restrict__ cand, const int* __restrict__ n_retain,
-                                                      uint32_t* __restrict__ lvl_list, int* __restrict__ lvl_count,
+                                                      const KeyT* __restrict__ cand, const int* __restrict__ n_retain,
+                                                      KeyT* __restrict__ lvl_list, int* __restrict__ lvl_count,
                                                       int* __restrict__ err) {
-    __shared__ uint32_t buf[SEL_LCAP];
+    __shared__ KeyT buf[SEL_LCAP];
     __shared__ uint16_t lists[2 * SEL_LCAP];
     __shared__ int aux[ORB_MAX_CELLS_PER_LEVEL + 1];
     __shared__ int red[4];
@@ -479,7 +550,7 @@ __global__ __launch_bounds__(256) void k_level_select(const GeomDev* __restrict_
     const int nCells = L.nCells;
     const CellDesc* lc = cells + L.cell_base;
     const int* ret = n_retain + (long long)f * g->cells_per_frame + L.cell_base;
-    const uint32_t* fcand = cand + (long long)f * g->cand_per_frame;
+    const KeyT* fcand = cand + (long long)f * g->cand_per_frame;
 
     // ---- exclusive scan of nToRetain over the cells (consecutive cells per thread) ----------------
     {
@@ -507,16 +578,16 @@ __global__ __launch_bounds__(256) void k_level_select(const GeomDev* __restrict_
         __syncthreads();
     }
     int total = aux[nCells];
-    uint32_t* ll = lvl_list + (long long)f * g->lvl_per_frame + L.lvl_off;
+    KeyT* ll = lvl_list + (long long)f * g->lvl_per_frame + L.lvl_off;
     if (total > L.lvl_cap) {
         if (tid == 0) atomicOr(err, 2);
         total = L.lvl_cap;
     }
     const bool lstaged = total <= SEL_LCAP;
-    uint32_t* dst = lstaged ? buf : ll;
+    KeyT* dst = lstaged ? buf : ll;
     for (int c = wave; c < nCells; c += 4) {
         const int o = aux[c], r = aux[c + 1] - o;
-        const uint32_t* list = fcand + lc[c].cand_off;
+        const KeyT* list = fcand + lc[c].cand_off;
         const uint32_t add = ((uint32_t)lc[c].ini_y << 12) + (uint32_t)lc[c].ini_x;
         for (int i = lane; i < r; i += 64)
             if (o + i < total) dst[o + i] = list[i] + add;  // x, y of the cell image -> level coordinates
@@ -543,8 +614,10 @@ __global__ __launch_bounds__(256) void k_level_select(const GeomDev* __restrict_
 // ---------------------------------------------------------------------------------------------
 // Output slot s of a frame belongs to level l iff slot_base[l] <= s < slot_base[l] + quota[l];
 // k = s - slot_base[l] is the keypoint's rank inside the level list.
-__device__ __forceinline__ bool slot_to_key(const GeomDev* g, const uint32_t* lvl_list, const int* lvl_count, int f,
-                                            int slot, int& level, int& k, uint32_t& key, int& out_index) {
+// key_words = 1: 32-bit keys; 2: 64-bit keys (response bits in the upper word, returned in `hi`).
+__device__ __forceinline__ bool slot_to_key(const GeomDev* g, const uint32_t* lvl_list, int key_words, const int* lvl_count,
+                                            int f, int slot, int& level, int& k, uint32_t& key, uint32_t& hi,
+                                            int& out_index) {
     if (slot >= g->nfeatures) return false;
     int l = 0;
     while (l + 1 < g->nlevels && g->lv[l + 1].slot_base <= slot) l++;
@@ -555,7 +628,9 @@ __device__ __forceinline__ bool slot_to_key(const GeomDev* g, const uint32_t* lv
     for (int i = 0; i < l; i++) o += cnt[i];
     out_index = o + k;
     level = l;
-    key = lvl_list[(long long)f * g->lvl_per_frame + g->lv[l].lvl_off + k];
+    const long long e = ((long long)f * g->lvl_per_frame + g->lv[l].lvl_off + k) * key_words;
+    key = lvl_list[e];
+    hi = key_words == 2 ? lvl_list[e + 1] : 0u;
     return true;
 }
 
@@ -698,7 +773,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
 
 __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
                                                          const GeomDev* __restrict__ g,
-                                                         const uint32_t* __restrict__ lvl_list,
+                                                         const uint32_t* __restrict__ lvl_list, int key_words,
                                                          const int* __restrict__ lvl_count,
                                                          const uint32_t* __restrict__ otab, float* __restrict__ angles,
                                                          const int8_t* __restrict__ pattern,
@@ -715,8 +790,8 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
         n_out[f] = n;
     }
     int level, k, oi;
-    uint32_t key;
-    if (!slot_to_key(g, lvl_list, lvl_count, f, slot, level, k, key, oi)) return;
+    uint32_t key, hi;
+    if (!slot_to_key(g, lvl_list, key_words, lvl_count, f, slot, level, k, key, hi, oi)) return;
     const LevelGeom& L = g->lv[level];
     const int x = key & 0xfff, y = (key >> 12) & 0xfff;
     const int stride = L.stride;
@@ -795,7 +870,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
             case 1: w = __float_as_uint(level ? __fmul_rn((float)y, scale) : (float)y); break;
             case 2: w = __float_as_uint(L.kp_size); break;
             case 3: w = __float_as_uint(angle_deg); break;
-            case 4: w = __float_as_uint((float)(key >> 24)); break;
+            case 4: w = key_words == 2 ? __float_as_uint(ordered_to_float(hi)) : __float_as_uint((float)(key >> 24)); break;
             case 5: w = (uint32_t)level; break;
             default: w = 0xffffffffu; break;
         }
@@ -880,8 +955,20 @@ void launch_select(hipStream_t st, const GeomDev& hg, int batch, const GeomDev* 
                    uint32_t* cand, const int* n_total, int* n_retain, uint32_t* lvl_list, int* lvl_count, int* err) {
     dim3 per_level(hg.nlevels, batch), per_cell((hg.cells_per_frame + 3) / 4, batch), block(256);
     hipLaunchKernelGGL(k_quota, per_level, block, 0, st, dg, cells, n_total, n_retain);
-    hipLaunchKernelGGL(k_cell_select, per_cell, block, 0, st, dg, cells, cand, n_total, n_retain);
-    hipLaunchKernelGGL(k_level_select, per_level, block, 0, st, dg, cells, cand, n_retain, lvl_list, lvl_count, err);
+    hipLaunchKernelGGL(k_cell_select<uint32_t>, per_cell, block, 0, st, dg, cells, cand, n_total, n_retain);
+    hipLaunchKernelGGL(k_level_select<uint32_t>, per_level, block, 0, st, dg, cells, cand, n_retain, lvl_list, lvl_count, err);
+}
+
+void launch_harris_select(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* pyr, const GeomDev* dg,
+                          const CellDesc* cells, const uint32_t* cand, uint64_t* cand64, const int* n_total, int* n_retain,
+                          uint64_t* lvl_list64, int* lvl_count, int* err) {
+    dim3 per_level(hg.nlevels, batch), per_cell4((hg.cells_per_frame + 3) / 4, batch), per_cell(hg.cells_per_frame, batch),
+        block(256);
+    hipLaunchKernelGGL(k_harris, per_cell, block, 0, st, pyr, dg, cells, cand, n_total, cand64);
+    hipLaunchKernelGGL(k_quota, per_level, block, 0, st, dg, cells, n_total, n_retain);
+    hipLaunchKernelGGL(k_cell_select<uint64_t>, per_cell4, block, 0, st, dg, cells, cand64, n_total, n_retain);
+    hipLaunchKernelGGL(k_level_select<uint64_t>, per_level, block, 0, st, dg, cells, cand64, n_retain, lvl_list64, lvl_count,
+                       err);
 }
 
 void launch_blur(hipStream_t st, const GeomDev& hg, int batch, int level, const uint8_t* pyr, uint8_t* blur,
@@ -892,12 +979,12 @@ void launch_blur(hipStream_t st, const GeomDev& hg, int batch, int level, const 
 }
 
 void launch_orient_describe(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* pyr, const uint8_t* blur,
-                            const GeomDev* dg, const uint32_t* lvl_list, const int* lvl_count, const uint32_t* otab,
-                            float* angles, const int8_t* pattern, OrbKeypointDev* kp_out, uint8_t* desc_out, int* n_out,
-                            int cap) {
+                            const GeomDev* dg, const uint32_t* lvl_list, int key_words, const int* lvl_count,
+                            const uint32_t* otab, float* angles, const int8_t* pattern, OrbKeypointDev* kp_out,
+                            uint8_t* desc_out, int* n_out, int cap) {
     dim3 grid((hg.nfeatures + 7) / 8, batch), block(256);
-    hipLaunchKernelGGL(k_orient_describe, grid, block, 0, st, pyr, blur, dg, lvl_list, lvl_count, otab, angles, pattern,
-                       kp_out, desc_out, n_out, cap);
+    hipLaunchKernelGGL(k_orient_describe, grid, block, 0, st, pyr, blur, dg, lvl_list, key_words, lvl_count, otab, angles,
+                       pattern, kp_out, desc_out, n_out, cap);
 }
 
 void launch_test_atan2(hipStream_t st, const float* yx, float* out, int n) {

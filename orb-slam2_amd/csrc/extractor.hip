@@ -26,6 +26,8 @@ const signed char kPattern[1024] = {
 inline int round_half_even(double v) { return (int)std::nearbyint(v); }  // cvRound
 inline int floor_int(double v) { int i = (int)v; return i - (i > v); }
 inline int ceil_int(double v) { int i = (int)v; return i + (i < v); }
+// inverse of the order-preserving float -> unsigned map of the HARRIS_SCORE keys: IEEE bits of the response
+inline uint32_t ordered_bits_to_float_bits(uint32_t u) { return (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; }
 
 struct DeviceBuf {
     void* p = nullptr;
@@ -84,7 +86,7 @@ struct orbhip_extractor {
     int last_batch = 0;  // frames of the last chunk (for the stage taps)
 
     DeviceBuf d_geom, d_cells, d_xofs, d_xab, d_ysrc, d_yab, d_disc, d_pattern;
-    DeviceBuf d_pyr, d_blur, d_score, d_cand, d_ntotal, d_nretain, d_lvl, d_lvlcount, d_angles, d_err;
+    DeviceBuf d_pyr, d_blur, d_score, d_cand, d_cand64, d_ntotal, d_nretain, d_lvl, d_lvlcount, d_angles, d_err;
     DeviceBuf d_img, d_kp, d_desc, d_n;  // staging of the host-pointer entry points
 };
 
@@ -311,7 +313,10 @@ int set_size(orbhip_extractor* e, int rows, int cols, int batch) {
     if ((rc = e->d_cand.ensure(std::max<size_t>(B * g.cand_per_frame * 4, 16)))) return rc;
     if ((rc = e->d_ntotal.ensure(B * g.cells_per_frame * 4))) return rc;
     if ((rc = e->d_nretain.ensure(B * g.cells_per_frame * 4))) return rc;
-    if ((rc = e->d_lvl.ensure(std::max<size_t>(B * g.lvl_per_frame * 4, 16)))) return rc;
+    // HARRIS_SCORE: 64-bit keys (float response above the 32-bit key) for the selection and its output
+    const size_t key_bytes = e->scoreType == ORBHIP_HARRIS_SCORE ? 8 : 4;
+    if (key_bytes == 8 && (rc = e->d_cand64.ensure(std::max<size_t>(B * g.cand_per_frame * 8, 16)))) return rc;
+    if ((rc = e->d_lvl.ensure(std::max<size_t>(B * g.lvl_per_frame * key_bytes, 16)))) return rc;
     if ((rc = e->d_lvlcount.ensure(B * g.nlevels * 4))) return rc;
     if ((rc = e->d_angles.ensure(B * g.nfeatures * 4))) return rc;
     return ORBHIP_OK;
@@ -329,7 +334,9 @@ int run_chunk(orbhip_extractor* e, hipStream_t st, int slot0, const uint8_t* d_i
     uint32_t* cand = e->d_cand.as<uint32_t>() + (size_t)slot0 * g.cand_per_frame;
     int* ntotal = e->d_ntotal.as<int>() + (size_t)slot0 * g.cells_per_frame;
     int* nretain = e->d_nretain.as<int>() + (size_t)slot0 * g.cells_per_frame;
-    uint32_t* lvl = e->d_lvl.as<uint32_t>() + (size_t)slot0 * g.lvl_per_frame;
+    const bool harris = e->scoreType == ORBHIP_HARRIS_SCORE;
+    const int key_words = harris ? 2 : 1;
+    uint32_t* lvl = e->d_lvl.as<uint32_t>() + (size_t)slot0 * g.lvl_per_frame * key_words;
     int* lvlcount = e->d_lvlcount.as<int>() + (size_t)slot0 * g.nlevels;
     float* angles = e->d_angles.as<float>() + (size_t)slot0 * g.nfeatures;
     hipEvent_t* pev = nullptr;
@@ -360,12 +367,17 @@ int run_chunk(orbhip_extractor* e, hipStream_t st, int slot0, const uint8_t* d_i
     else
         orbk::launch_nms(st, g, batch, e->max_cell_h, score, dg, e->d_cells.as<CellDesc>(), cand, ntotal, e->d_err.as<int>());
     STAGE_MARK(4);
-    orbk::launch_select(st, g, batch, dg, e->d_cells.as<CellDesc>(), cand, ntotal, nretain, lvl, lvlcount, e->d_err.as<int>());
+    if (harris)
+        orbk::launch_harris_select(st, g, batch, pyr, dg, e->d_cells.as<CellDesc>(), cand,
+                                   e->d_cand64.as<uint64_t>() + (size_t)slot0 * g.cand_per_frame, ntotal, nretain,
+                                   (uint64_t*)lvl, lvlcount, e->d_err.as<int>());
+    else
+        orbk::launch_select(st, g, batch, dg, e->d_cells.as<CellDesc>(), cand, ntotal, nretain, lvl, lvlcount, e->d_err.as<int>());
     STAGE_MARK(5);
     STAGE_MARK(6);  // the orientation is computed by the descriptor kernel
     for (int l = 0; l < g.nlevels; l++) orbk::launch_blur(st, g, batch, l, pyr, blur, dg, e->gtaps);
     STAGE_MARK(7);
-    orbk::launch_orient_describe(st, g, batch, pyr, blur, dg, lvl, lvlcount, e->d_disc.as<uint32_t>(), angles,
+    orbk::launch_orient_describe(st, g, batch, pyr, blur, dg, lvl, key_words, lvlcount, e->d_disc.as<uint32_t>(), angles,
                                  e->d_pattern.as<int8_t>(), (OrbKeypointDev*)d_kp, d_desc, d_n, cap);
     STAGE_MARK(8);
 #undef STAGE_MARK
@@ -377,7 +389,6 @@ int check_call(orbhip_extractor* e, int batch, int rows, int cols, int cap) {
     if (!e) return orb_fail(ORBHIP_EINVAL, "null extractor");
     if (batch < 0 || rows < 0 || cols < 0) return orb_fail(ORBHIP_EINVAL, "negative size");
     if (cap < e->nfeatures) return orb_fail(ORBHIP_ECAP, "cap %d < nfeatures %d", cap, e->nfeatures);
-    if (e->scoreType != ORBHIP_FAST_SCORE) return orb_fail(ORBHIP_EUNSUPPORTED, "HARRIS_SCORE is not implemented");
     return ORBHIP_OK;
 }
 
@@ -487,7 +498,7 @@ void orbhip_extractor_destroy(orbhip_extractor* e) {
     hipSetDevice(e->device);
     if (e->stream) hipStreamSynchronize(e->stream);
     DeviceBuf* bufs[] = {&e->d_geom, &e->d_cells, &e->d_xofs, &e->d_xab, &e->d_ysrc, &e->d_yab, &e->d_disc, &e->d_pattern,
-                         &e->d_pyr, &e->d_blur, &e->d_score, &e->d_cand, &e->d_ntotal, &e->d_nretain, &e->d_lvl,
+                         &e->d_pyr, &e->d_blur, &e->d_score, &e->d_cand, &e->d_cand64, &e->d_ntotal, &e->d_nretain, &e->d_lvl,
                          &e->d_lvlcount, &e->d_angles, &e->d_err, &e->d_img, &e->d_kp, &e->d_desc, &e->d_n};
     for (DeviceBuf* b : bufs) b->release();
     for (hipEvent_t ev : e->prof_ev) hipEventDestroy(ev);
@@ -567,7 +578,7 @@ int orbhip_extractor_synchronize(orbhip_extractor* e) {
     }
     if (e->profiling) {
         const int nl = e->nlevels;
-        const int per_chunk[ORB_NSTAGES] = {1, nl - 1, e->fused_fast ? 0 : nl, 1, 3, 0, nl, 1};
+        const int per_chunk[ORB_NSTAGES] = {1, nl - 1, e->fused_fast ? 0 : nl, 1, e->scoreType == ORBHIP_HARRIS_SCORE ? 4 : 3, 0, nl, 1};
         for (int s = 0; s < ORB_NSTAGES; s++) {
             e->stage_ms[s] = 0.f;
             e->stage_launches[s] = per_chunk[s] * e->prof_chunks;
@@ -679,15 +690,17 @@ int orbhip_debug_get(orbhip_extractor* e, int stage, int frame, int level, void*
         int count = 0;
         HIPCHK(hipMemcpy(&count, e->d_lvlcount.as<int>() + (size_t)frame * g.nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
         if (buf_bytes < sizeof(int) * 3 * (size_t)count) return orb_fail(ORBHIP_ECAP, "tap buffer too small");
-        std::vector<uint32_t> keys(count);
+        const int kw = e->scoreType == ORBHIP_HARRIS_SCORE ? 2 : 1;
+        std::vector<uint32_t> keys((size_t)count * kw);
         if (count)
-            HIPCHK(hipMemcpy(keys.data(), e->d_lvl.as<uint32_t>() + (size_t)frame * g.lvl_per_frame + L.lvl_off,
-                             sizeof(uint32_t) * count, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(keys.data(), e->d_lvl.as<uint32_t>() + ((size_t)frame * g.lvl_per_frame + L.lvl_off) * kw,
+                             sizeof(uint32_t) * count * kw, hipMemcpyDeviceToHost));
         int* o = (int*)buf;
         for (int i = 0; i < count; i++) {
-            o[3 * i] = keys[i] & 0xfff;
-            o[3 * i + 1] = (keys[i] >> 12) & 0xfff;
-            o[3 * i + 2] = keys[i] >> 24;
+            const uint32_t key = keys[(size_t)i * kw];
+            o[3 * i] = key & 0xfff;
+            o[3 * i + 1] = (key >> 12) & 0xfff;
+            o[3 * i + 2] = kw == 2 ? (int)ordered_bits_to_float_bits(keys[(size_t)i * kw + 1]) : (int)(key >> 24);
         }
         return count;
     }
@@ -699,17 +712,20 @@ int orbhip_debug_get(orbhip_extractor* e, int stage, int frame, int level, void*
         for (int c = 0; c < L.nCells; c++) total += counts[c];
         if (buf_bytes < sizeof(int) * 3 * total) return orb_fail(ORBHIP_ECAP, "tap buffer too small");
         int* o = (int*)buf;
+        const int kw = e->scoreType == ORBHIP_HARRIS_SCORE ? 2 : 1;
+        const DeviceBuf& arena = kw == 2 ? e->d_cand64 : e->d_cand;
         std::vector<uint32_t> keys;
         for (int c = 0; c < L.nCells; c++) {
             const CellDesc& cd = e->hcells[L.cell_base + c];
-            keys.resize(counts[c]);
+            keys.resize((size_t)counts[c] * kw);
             if (counts[c])
-                HIPCHK(hipMemcpy(keys.data(), e->d_cand.as<uint32_t>() + (size_t)frame * g.cand_per_frame + cd.cand_off,
-                                 sizeof(uint32_t) * counts[c], hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(keys.data(), arena.as<uint32_t>() + ((size_t)frame * g.cand_per_frame + cd.cand_off) * kw,
+                                 sizeof(uint32_t) * counts[c] * kw, hipMemcpyDeviceToHost));
             for (int i = 0; i < counts[c]; i++) {
-                *o++ = keys[i] & 0xfff;
-                *o++ = (keys[i] >> 12) & 0xfff;
-                *o++ = keys[i] >> 24;
+                const uint32_t key = keys[(size_t)i * kw];
+                *o++ = key & 0xfff;
+                *o++ = (key >> 12) & 0xfff;
+                *o++ = kw == 2 ? (int)ordered_bits_to_float_bits(keys[(size_t)i * kw + 1]) : (int)(key >> 24);
             }
         }
         return (int)total;

@@ -5,8 +5,12 @@
 // of several equal-score keypoints survive and the order they come out in are defined by that
 // algorithm's swap sequence.  FAST scores are small integers and ties are the norm.
 //
-// Elements are 32-bit keys: score in bits 31..24, payload (coordinates) below; the comparator
-// is the reference's "response greater" and looks at the score only.
+// Elements are keys whose top bits hold the response and whose low bits hold the payload
+// (coordinates); the comparator is the reference's "response greater" and looks at the response
+// only.  Two key formats:
+//   uint32_t  FAST score (an integer < 256) in bits 31..24;
+//   uint64_t  any float response, mapped to an unsigned integer of the same order, in bits 63..32
+//             (HARRIS_SCORE, src/ORBextractor.cc:616-620).
 #ifndef ORBHIP_INTROSELECT_H
 #define ORBHIP_INTROSELECT_H
 #include <stdint.h>
@@ -14,11 +18,18 @@
 
 namespace orbsel {
 
-ORB_HD inline bool score_gt(uint32_t a, uint32_t b) { return (a >> 24) > (b >> 24); }
+ORB_HD inline uint32_t score_of(uint32_t k) { return k >> 24; }
+ORB_HD inline uint32_t score_of(uint64_t k) { return (uint32_t)(k >> 32); }
+ORB_HD inline bool score_gt(uint32_t a, uint32_t b) { return score_of(a) > score_of(b); }
+ORB_HD inline bool score_gt(uint64_t a, uint64_t b) { return score_of(a) > score_of(b); }
+
+// element type behind a pointer-like P
+template <class P> struct elem_of;
+template <class T> struct elem_of<T*> { typedef T type; };
 
 template <class P>
 ORB_HD inline void swap_at(P v, int i, int j) {
-    uint32_t t = v[i];
+    typename elem_of<P>::type t = v[i];
     v[i] = v[j];
     v[j] = t;
 }
@@ -26,7 +37,7 @@ ORB_HD inline void swap_at(P v, int i, int j) {
 // Median of v[a], v[b], v[c] under score_gt goes to v[dst].
 template <class P>
 ORB_HD inline void median_to(P v, int dst, int a, int b, int c) {
-    uint32_t va = v[a], vb = v[b], vc = v[c];
+    typename elem_of<P>::type va = v[a], vb = v[b], vc = v[c];
     int m;
     if (score_gt(va, vb)) {
         if (score_gt(vb, vc)) m = b;
@@ -41,7 +52,7 @@ ORB_HD inline void median_to(P v, int dst, int a, int b, int c) {
 // Hoare partition of [first, last) around pivot (a value, held outside the range); both scans
 // are unguarded and rely on the median-of-three sentinels.
 template <class P>
-ORB_HD inline int partition_unguarded(P v, int first, int last, uint32_t pivot) {
+ORB_HD inline int partition_unguarded(P v, int first, int last, typename elem_of<P>::type pivot) {
     for (;;) {
         while (score_gt(v[first], pivot)) ++first;
         --last;
@@ -55,7 +66,7 @@ ORB_HD inline int partition_unguarded(P v, int first, int last, uint32_t pivot) 
 // Sift `value` down from `hole` in the heap v[base .. base+len), then back up (libstdc++'s
 // __adjust_heap followed by its __push_heap).
 template <class P>
-ORB_HD inline void heap_adjust(P v, int base, int hole, int len, uint32_t value) {
+ORB_HD inline void heap_adjust(P v, int base, int hole, int len, typename elem_of<P>::type value) {
     const int top = hole;
     int child = hole;
     while (child < (len - 1) / 2) {
@@ -84,7 +95,7 @@ ORB_HD inline void heap_select(P v, int first, int middle, int last) {
     if (len >= 2) {
         int parent = (len - 2) / 2;
         for (;;) {
-            uint32_t value = v[first + parent];
+            typename elem_of<P>::type value = v[first + parent];
             heap_adjust(v, first, parent, len, value);
             if (parent == 0) break;
             parent--;
@@ -92,7 +103,7 @@ ORB_HD inline void heap_select(P v, int first, int middle, int last) {
     }
     for (int i = middle; i < last; ++i)
         if (score_gt(v[i], v[first])) {
-            uint32_t value = v[i];
+            typename elem_of<P>::type value = v[i];
             v[i] = v[first];
             heap_adjust(v, first, 0, len, value);
         }
@@ -102,7 +113,7 @@ template <class P>
 ORB_HD inline void insertion_sort(P v, int first, int last) {
     if (first == last) return;
     for (int i = first + 1; i != last; ++i) {
-        uint32_t val = v[i];
+        typename elem_of<P>::type val = v[i];
         if (score_gt(val, v[first])) {
             for (int k = i; k > first; --k) v[k] = v[k - 1];
             v[first] = val;

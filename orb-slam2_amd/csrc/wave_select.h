@@ -1,5 +1,5 @@
 // Wave-cooperative form of the selection in introselect.h: the same element movement as
-// libstdc++'s std::nth_element (response-greater comparator on the score byte of 32-bit keys),
+// libstdc++'s std::nth_element (response-greater comparator on the response bits of the keys),
 // with the Hoare partition of each introselect round evaluated by the 64 lanes of one wave.
 //
 // Why the partition can be done in parallel and still move elements exactly like the serial scan:
@@ -27,7 +27,8 @@ __device__ __forceinline__ int lane_prefix64(unsigned long long mask) {
 }
 __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
-__device__ inline void wave_nth_element_desc(uint32_t* v, int n, int nth, uint16_t* lpos, uint16_t* rpos, int lane,
+template <class KeyT>
+__device__ inline void wave_nth_element_desc(KeyT* v, int n, int nth, uint16_t* lpos, uint16_t* rpos, int lane,
                                              int depth_limit = -1) {
     if (n == 0 || nth == n) return;
     int first = 0, last = n;
@@ -45,13 +46,13 @@ __device__ inline void wave_nth_element_desc(uint32_t* v, int n, int nth, uint16
         const int mid = first + (last - first) / 2;
         if (lane == 0) median_to(v, first, first + 1, mid, last - 1);
         wave_lds_fence();
-        const uint32_t ps = v[first] >> 24;
+        const uint32_t ps = score_of(v[first]);
         const int lo = first + 1, hi = last;
         int nL = 0, nR = 0;
         for (int base = lo; base < hi; base += 64) {
             const int i = base + lane;
             const bool in = i < hi;
-            const uint32_t sc = in ? (v[i] >> 24) : 0u;
+            const uint32_t sc = in ? score_of(v[i]) : 0u;
             const bool isL = in && !(sc > ps);
             const bool isR = in && !(ps > sc);
             const unsigned long long mL = __ballot(isL), mR = __ballot(isR);
@@ -72,7 +73,7 @@ __device__ inline void wave_nth_element_desc(uint32_t* v, int n, int nth, uint16
         }
         for (int k = lane; k < K; k += 64) {
             const int a = lpos[k], b = rpos[nR - 1 - k];
-            const uint32_t ta = v[a], tb = v[b];
+            const KeyT ta = v[a], tb = v[b];
             v[a] = tb;
             v[b] = ta;
         }

@@ -89,6 +89,40 @@ static int test_select() {
                 for (int i = 0; i < n; i++)
                     if ((int)(a[i] & 0xffffff) != b[i].id) { bad++; break; }
             }
+    // 64-bit keys: float responses (negative, fractional, tied) through the order-preserving map
+    for (int n : {1, 4, 17, 100, 999, 3000})
+        for (int rep = 0; rep < 30; rep++) {
+            std::vector<uint64_t> keys(n);
+            std::vector<KP> ref(n);
+            for (int i = 0; i < n; i++) {
+                float r;
+                switch (rep % 3) {
+                    case 0: r = ((int)(rng() % 2001) - 1000) * 1e-7f; break;        // Harris-like, many ties
+                    case 1: r = std::ldexp((float)(int)(rng() % 65536) - 32768.f, (int)(rng() % 40) - 30); break;
+                    default: r = (rng() % 3 == 0) ? 0.f : ((rng() & 1) ? 1.5e-6f : -2.25e-5f); break;
+                }
+                uint32_t u;
+                memcpy(&u, &r, 4);
+                const uint32_t ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                keys[i] = ((uint64_t)ord << 32) | (uint32_t)i;
+                ref[i].response = r;
+                ref[i].id = i;
+            }
+            for (int k : {0, n / 5, n / 2, n - 1}) {
+                if (k < 0 || k >= n) continue;
+                for (int depth : {-1, 1}) {
+                    std::vector<uint64_t> a = keys;
+                    std::vector<KP> b = ref;
+                    orbsel::nth_element_desc(a.data(), n, k, depth);
+                    if (depth < 0) std::nth_element(b.begin(), b.begin() + k, b.end(), Greater());
+                    else if (b.begin() + k != b.end())
+                        std::__introselect(b.begin(), b.begin() + k, b.end(), depth, __gnu_cxx::__ops::__iter_comp_iter(Greater()));
+                    cases++;
+                    for (int i = 0; i < n; i++)
+                        if ((int)(a[i] & 0xffffff) != b[i].id) { bad++; break; }
+                }
+            }
+        }
     printf("select: %d cases, %d mismatching permutations\n", cases, bad);
     return bad;
 }

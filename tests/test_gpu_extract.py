@@ -167,3 +167,47 @@ def test_empty_image_and_errors(orb):
     assert ei.value.code == -5
     with pytest.raises(orb.OrbhipError):
         orb.ORBextractor(0, 1.2, 8, 1, 20)
+
+
+HARRIS_CASES = [(640, 480, 1000, 8, 20, 0), (1280, 720, 2000, 8, 20, 2), (320, 240, 500, 6, 12, 5)]
+
+
+@pytest.mark.parametrize("case", HARRIS_CASES)
+def test_harris_score(orb, orbref, synth, case):
+    """scoreType = HARRIS_SCORE (src/ORBextractor.cc:616-620): the float Harris response replaces the FAST
+    score before the quota / retainBest selection.  Responses are compared as IEEE bits."""
+    w, h, nf, nl, th, fi = case
+    dev = orb.ORBextractor(nf, 1.2, nl, orb.ORBextractor.HARRIS_SCORE, th, device=0, max_width=w, max_height=h)
+    ref = orbref.RefExtractor(nf, 1.2, nl, 0, th)
+    img = synth.synth_image(w, h, fi)
+    rkp, rdesc = ref(img)
+    dkp, ddesc = dev(img)
+    for l in range(nl):
+        counts, cand = ref.level_candidates(l)
+        assert np.array_equal(counts, dev.tap_cells(3, 0, l)), "level %d candidate counts" % l
+        dcand = dev.tap_candidates(0, l)
+        o = 0
+        for c, n in enumerate(counts):  # same candidates with the same response bits, as a set per cell
+            assert sorted(map(tuple, cand[o:o + n])) == sorted(map(tuple, dcand[o:o + n])), "level %d cell %d" % (l, c)
+            o += n
+        assert np.array_equal(ref.level_retain(l), dev.tap_cells(4, 0, l)), "level %d nToRetain" % l
+        assert np.array_equal(ref.level_keypoints(l), dev.tap_level_keypoints(0, l)), "level %d selection" % l
+    _assert_same(rkp, rdesc, dkp, ddesc)
+    assert len(rkp) > nf // 2
+    assert (rkp["response"] != np.round(rkp["response"])).any()  # these are Harris floats, not FAST integers
+
+
+def test_harris_batch_and_mode_switch(orb, orbref, synth):
+    """A batch through the Harris path, then a FAST-score extractor in the same process."""
+    w, h, nf = 640, 480, 800
+    imgs = np.stack([synth.synth_image(w, h, 20 + i) for i in range(5)])
+    dev = orb.ORBextractor(nf, 1.2, 8, 0, 20, device=0, max_width=w, max_height=h, max_batch=2)
+    ref = orbref.RefExtractor(nf, 1.2, 8, 0, 20)
+    out = dev.extract_batch(imgs)
+    for i in range(5):
+        rkp, rdesc = ref(imgs[i])
+        _assert_same(rkp, rdesc, out[i][0], out[i][1])
+    devf = orb.ORBextractor(nf, 1.2, 8, 1, 20, device=0, max_width=w, max_height=h)
+    rkp, rdesc = orbref.RefExtractor(nf, 1.2, 8, 1, 20)(imgs[0])
+    dkp, ddesc = devf(imgs[0])
+    _assert_same(rkp, rdesc, dkp, ddesc)
