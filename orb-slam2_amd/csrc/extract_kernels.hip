@@ -26,33 +26,44 @@ __device__ __forceinline__ int reflect101(int p, int n) {
 
 // ---------------------------------------------------------------------------------------------
 // Level 0: copyMakeBorder(image, temp, 16.., BORDER_REFLECT_101) (src/ORBextractor.cc:814).
-// One thread writes one aligned dword of the padded plane.
+// One thread writes 16 aligned bytes of the padded plane.  The border is 16 px wide, so an interior
+// group is a 16-byte run of the source row at a multiple of 16: one 16-byte load when the source
+// rows are 16-byte aligned (`wide`), else four (possibly unaligned) dwords; groups that touch the
+// border are assembled bytewise through the reflection.
 __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ imgs, long long frame_stride,
                                                 long long row_stride, uint8_t* __restrict__ pyr,
-                                                const GeomDev* __restrict__ g) {
+                                                const GeomDev* __restrict__ g, int wide) {
     const LevelGeom& L = g->lv[0];
-    const int dwx = blockIdx.x * 64 + threadIdx.x;
-    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int gx = blockIdx.x * 32 + threadIdx.x;  // 16-byte group of the padded row
+    const int y = blockIdx.y * 8 + threadIdx.y;
     const int f = blockIdx.z;
-    if (dwx * 4 >= L.stride || y >= L.ph) return;
+    if (gx * 16 >= L.stride || y >= L.ph) return;
     const uint8_t* src = imgs + (long long)f * frame_stride;
     const int sy = reflect101(y - ORB_EDGE, L.h);
     const uint8_t* srow = src + (long long)sy * row_stride;
-    const int x0 = dwx * 4 - ORB_EDGE;  // source column of the dword's first pixel
-    uint32_t out;
-    if (x0 >= 0 && x0 + 3 < L.w) {
-        out = *(const u32_unaligned*)(srow + x0);  // interior: one (possibly unaligned) dword
+    const int x0 = gx * 16 - ORB_EDGE;  // source column of the group's first pixel
+    uint4 out;
+    if (x0 >= 0 && x0 + 15 < L.w) {
+        if (wide) {
+            out = *(const uint4*)(srow + x0);
+        } else {
+            out.x = *(const u32_unaligned*)(srow + x0);
+            out.y = *(const u32_unaligned*)(srow + x0 + 4);
+            out.z = *(const u32_unaligned*)(srow + x0 + 8);
+            out.w = *(const u32_unaligned*)(srow + x0 + 12);
+        }
     } else {
-        out = 0;
+        uint32_t wds[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const int x = dwx * 4 + b;
+        for (int b = 0; b < 16; b++) {
+            const int x = gx * 16 + b;
             uint32_t v = 0;
             if (x < L.w + 2 * ORB_EDGE) v = srow[reflect101(x - ORB_EDGE, L.w)];
-            out |= v << (8 * b);
+            wds[b >> 2] |= v << (8 * (b & 3));
         }
+        out = make_uint4(wds[0], wds[1], wds[2], wds[3]);
     }
-    *(uint32_t*)(pyr + (long long)f * g->frame_bytes + L.plane_off + (long long)y * L.stride + dwx * 4) = out;
+    *(uint4*)(pyr + (long long)f * g->frame_bytes + L.plane_off + (long long)y * L.stride + gx * 16) = out;
 }
 
 // Level l >= 1: resize(level l-1 ROI -> level l ROI, INTER_LINEAR) then copyMakeBorder
@@ -917,8 +928,9 @@ namespace orbk {
 void launch_level0(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* imgs, long long frame_stride,
                    long long row_stride, uint8_t* pyr, const GeomDev* dg) {
     const LevelGeom& L = hg.lv[0];
-    dim3 grid((L.stride / 4 + 63) / 64, (L.ph + 3) / 4, batch), block(64, 4);
-    hipLaunchKernelGGL(k_level0, grid, block, 0, st, imgs, frame_stride, row_stride, pyr, dg);
+    const int wide = ((uintptr_t)imgs % 16 == 0) && (row_stride % 16 == 0) && (frame_stride % 16 == 0);
+    dim3 grid((L.stride / 16 + 31) / 32, (L.ph + 7) / 8, batch), block(32, 8);
+    hipLaunchKernelGGL(k_level0, grid, block, 0, st, imgs, frame_stride, row_stride, pyr, dg, wide);
 }
 
 void launch_resize(hipStream_t st, const GeomDev& hg, int batch, int level, uint8_t* pyr, const GeomDev* dg,

@@ -323,8 +323,6 @@ int orbhip_knn2(orbhip_matcher* m, const uint8_t* q, int nq, const uint8_t* t, i
     if (need > m->stage_bytes) {
         HIPCHK(hipStreamSynchronize(m->stream));
         if (m->d_stage) hipFree(m->d_stage);
-    if (m->d_work) hipFree(m->d_work);
-    if (m->d_err) hipFree(m->d_err);
         m->d_stage = nullptr;
         m->stage_bytes = 0;
         if (hipMalloc(&m->d_stage, need) != hipSuccess) return orb_fail(ORBHIP_ENOMEM, "hipMalloc of %zu bytes failed", need);

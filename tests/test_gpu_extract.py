@@ -16,6 +16,7 @@ CASES = [
     (1280, 720, 2000, 8, 20, 2),
     (752, 480, 1500, 8, 12, 3),
     (500, 375, 800, 5, 30, 4),
+    (1920, 1080, 4000, 8, 20, 9),
 ]
 
 
