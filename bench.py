@@ -320,6 +320,27 @@ def extra_legs(orb, torch, dev, threads):
                            "cpu_oracle_1_thread_comparisons_per_sec": float("%.4g" % (nq * nt / cdt)),
                            "parity_pair0": bool(np.array_equal(oo[0], ridx) and np.array_equal(oo[1], rd1)
                                                 and np.array_equal(oo[2], rd2))}
+    # frame-vs-map shard: 4000 queries against the 1.25 M map descriptors one GPU of eight would own
+    nq2, nt2 = 4000, 1250000
+    q2 = torch.randint(0, 256, (nq2, 32), dtype=torch.uint8, device="cuda:%d" % dev, generator=g)
+    t2 = torch.randint(0, 256, (nt2, 32), dtype=torch.uint8, device="cuda:%d" % dev, generator=g)
+    o2 = torch.zeros((3, nq2), dtype=torch.int32, device="cuda:%d" % dev)
+    torch.cuda.synchronize(dev)
+    ms2 = []
+    for _ in range(4):
+        m.knn2_device(q2.data_ptr(), nq2, 0, t2.data_ptr(), nt2, 0, 1, 0, o2[0].data_ptr(), o2[1].data_ptr(), o2[2].data_ptr())
+        m.synchronize()
+        ms2.append(m.last_elapsed_ms())
+    best2 = float(np.median(ms2[1:]))
+    # spot check of 8 queries against the scalar scan
+    hq2, ht2 = q2[:8].cpu().numpy(), t2.cpu().numpy()
+    r_idx, r_d1, r_d2 = orbref.knn2(hq2, ht2)
+    oo2 = o2[:, :8].cpu().numpy()
+    res["hamming_knn2_map_shard"] = {"nq": nq2, "nt": nt2, "ms": round(best2, 4),
+                                     "comparisons_per_sec": float("%.4g" % (nq2 * nt2 / (best2 * 1e-3))),
+                                     "parity_first_8_queries": bool(np.array_equal(oo2[0], r_idx) and np.array_equal(oo2[1], r_d1)
+                                                                    and np.array_equal(oo2[2], r_d2))}
+    del q2, t2
     res["windowed_matchers"] = windowed_leg(orb, torch, dev, orbref)
     return res
 

@@ -762,7 +762,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
 
 // ---------------------------------------------------------------------------------------------
 // IC_Angle (src/ORBextractor.cc:124-151) + computeOrbDescriptor (:154-194) + the output record of
-// operator() (:769-777) in one kernel, 32 lanes (half a wave) per keypoint, so that the chain of
+// operator() (:769-777) in one kernel, OD_LPK lanes per keypoint, so that the chain of
 // dependent memory round trips (level counts -> key -> pixels) is paid once per keypoint.
 //
 // Orientation: intensity-centroid moments over the radius-15 disc of the UNBLURRED level image.
@@ -772,15 +772,22 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
 //   sum(u * I) = dot4(I, u + 16) - 16 * dot4(I, mask),   sum(v * I) = v * dot4(I, mask).
 // The moments are exact integers whatever the summation order.
 //
-// Descriptor: lane i produces descriptor byte i (8 tests) from the BLURRED plane.  The rotated
+// Descriptor: lane i produces descriptor bytes i*OD_BYTES .. (8 tests each) from the BLURRED plane.  The rotated
 // pattern reaches at most 18 px from the keypoint (largest pattern radius 18.38), so the 37 x 37
-// window around it is copied to LDS with row-contiguous dword loads (37 rows of 10 unaligned
+// window around it is copied to LDS with row-contiguous aligned dword loads (37 rows of 11
 // dwords) and the 16 scattered samples of each lane are LDS byte reads; gathering them from
 // global memory instead costs one vector-cache tag lookup per lane and sample.
 #define DS_REACH 18
 #define DS_ROWS (2 * DS_REACH + 1)
-#define DS_DWORDS 10  // 37 bytes from an arbitrary byte address, rounded up to dwords
-#define DS_ITERS ((DS_ROWS * DS_DWORDS + 31) / 32)
+#define DS_DWORDS 11  // 37 bytes from an arbitrary byte address, as aligned dwords (up to 3 bytes of lead-in)
+// Lanes per keypoint.  Every lane of a keypoint computes the same fastAtan2 / cosf / sinf, so fewer
+// lanes per keypoint mean less redundant arithmetic per wave; 16 keeps the loads of one keypoint
+// row-contiguous (each lane then produces 2 descriptor bytes).
+#define OD_LPK 32
+#define OD_KPB (256 / OD_LPK)  // keypoints per workgroup
+#define OD_BYTES (32 / OD_LPK)  // descriptor bytes per lane
+#define DS_ITERS ((DS_ROWS * DS_DWORDS + OD_LPK - 1) / OD_LPK)
+#define OR_ITERS ((31 * 8 + OD_LPK - 1) / OD_LPK)
 
 __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
                                                          const GeomDev* __restrict__ g,
@@ -790,11 +797,11 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
                                                          const int8_t* __restrict__ pattern,
                                                          OrbKeypointDev* __restrict__ kp_out, uint8_t* __restrict__ desc_out,
                                                          int* __restrict__ n_out, int cap) {
-    __shared__ uint32_t ds_win[8][DS_ROWS * DS_DWORDS];
+    __shared__ uint32_t ds_win[OD_KPB][DS_ROWS * DS_DWORDS];
     int bx = blockIdx.x, f = blockIdx.y;
     xcd_frame_swizzle(bx, f, (int)gridDim.x, (int)gridDim.y);
-    const int slot = bx * 8 + (threadIdx.x >> 5);
-    const int li = threadIdx.x & 31;
+    const int slot = bx * OD_KPB + (threadIdx.x / OD_LPK);
+    const int li = threadIdx.x % OD_LPK;
     if (slot == 0 && li == 0) {
         int n = 0;
         for (int l = 0; l < g->nlevels; l++) n += lvl_count[f * g->nlevels + l];
@@ -810,25 +817,27 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
 
     // all loads of both windows are issued before anything waits on them
     const uint8_t* ocenter = pyr + pix;
-    uint32_t disc[8];
+    uint32_t disc[OR_ITERS];
 #pragma unroll
-    for (int it = 0; it < 8; it++) {
-        const int idx = min(it * 32 + li, 31 * 8 - 1);
+    for (int it = 0; it < OR_ITERS; it++) {
+        const int idx = min(it * OD_LPK + li, 31 * 8 - 1);
         disc[it] = *(const u32_unaligned*)(ocenter + ((idx >> 3) - ORB_HALF_PATCH) * stride - ORB_HALF_PATCH + 4 * (idx & 7));
     }
-    const uint8_t* corner = blur + pix - (long long)DS_REACH * stride - DS_REACH;
+    // window rows start at the dword at or before column x - 18 (planes and strides are 4-byte aligned)
+    const int lead = (int)((pix - DS_REACH) & 3);
+    const uint8_t* corner = blur + pix - (long long)DS_REACH * stride - DS_REACH - lead;
     uint32_t wreg[DS_ITERS];
 #pragma unroll
     for (int it = 0; it < DS_ITERS; it++) {
-        const int i = min(it * 32 + li, DS_ROWS * DS_DWORDS - 1);
+        const int i = min(it * OD_LPK + li, DS_ROWS * DS_DWORDS - 1);
         const int r = i / DS_DWORDS, cdw = i - r * DS_DWORDS;
-        wreg[it] = *(const u32_unaligned*)(corner + r * stride + 4 * cdw);
+        wreg[it] = *(const uint32_t*)(corner + r * stride + 4 * cdw);
     }
 
     int m10 = 0, m01 = 0;
 #pragma unroll
-    for (int it = 0; it < 8; it++) {
-        const int idx = it * 32 + li;
+    for (int it = 0; it < OR_ITERS; it++) {
+        const int idx = it * OD_LPK + li;
         if (idx < 31 * 8) {
             const int v = (idx >> 3) - ORB_HALF_PATCH;
             const uint2 w = ((const uint2*)otab)[idx];
@@ -839,29 +848,29 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
         }
     }
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) {
+    for (int o = OD_LPK / 2; o > 0; o >>= 1) {
         m10 += __shfl_xor(m10, o);
         m01 += __shfl_xor(m01, o);
     }
     const float angle_deg = fast_atan2_deg((float)m01, (float)m10);
     if (li == 0) angles[(long long)f * g->nfeatures + slot] = angle_deg;
 
-    uint32_t* win = ds_win[threadIdx.x >> 5];
+    uint32_t* win = ds_win[threadIdx.x / OD_LPK];
 #pragma unroll
     for (int it = 0; it < DS_ITERS; it++) {
-        const int i = it * 32 + li;
+        const int i = it * OD_LPK + li;
         if (i < DS_ROWS * DS_DWORDS) win[i] = wreg[it];
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the window is private to this half-wave
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the window is private to this keypoint's lanes
 
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float angle = angle_deg * factorPI;
     const float a = orbtrig::cos_f<false>(angle), b = orbtrig::sin_f<false>(angle);
-    const uint8_t* center = (const uint8_t*)win + DS_REACH * (4 * DS_DWORDS) + DS_REACH;
-    const int8_t* pat = pattern + li * 32;
+    const uint8_t* center = (const uint8_t*)win + DS_REACH * (4 * DS_DWORDS) + DS_REACH + lead;
+    const int8_t* pat = pattern + li * (32 * OD_BYTES);
     uint32_t val = 0;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
+    for (int j = 0; j < 8 * OD_BYTES; j++) {
         const float x0 = (float)pat[4 * j], y0 = (float)pat[4 * j + 1], x1 = (float)pat[4 * j + 2], y1 = (float)pat[4 * j + 3];
         const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
         const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
@@ -872,7 +881,9 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
     }
     if (oi >= cap) return;
     const long long o = (long long)f * cap + oi;
-    desc_out[o * 32 + li] = (uint8_t)val;
+    if (OD_BYTES == 1) desc_out[o * 32 + li] = (uint8_t)val;
+    else if (OD_BYTES == 2) ((uint16_t*)(desc_out + o * 32))[li] = (uint16_t)val;
+    else ((uint32_t*)(desc_out + o * 32))[li] = val;
     if (li < 7) {
         uint32_t w;
         const float scale = L.scale;
@@ -994,7 +1005,7 @@ void launch_orient_describe(hipStream_t st, const GeomDev& hg, int batch, const 
                             const GeomDev* dg, const uint32_t* lvl_list, int key_words, const int* lvl_count,
                             const uint32_t* otab, float* angles, const int8_t* pattern, OrbKeypointDev* kp_out,
                             uint8_t* desc_out, int* n_out, int cap) {
-    dim3 grid((hg.nfeatures + 7) / 8, batch), block(256);
+    dim3 grid((hg.nfeatures + OD_KPB - 1) / OD_KPB, batch), block(256);
     hipLaunchKernelGGL(k_orient_describe, grid, block, 0, st, pyr, blur, dg, lvl_list, key_words, lvl_count, otab, angles,
                        pattern, kp_out, desc_out, n_out, cap);
 }
