@@ -244,6 +244,26 @@ int orbhip_window_search(orbhip_matcher* m, const OrbKeypoint* kp1, const uint8_
 int orbhip_distinctive_descriptors_device(orbhip_matcher* m, const uint8_t* d_desc, const int32_t* d_start,
                                           int npoints, int32_t* d_best_idx, int32_t* d_best_median);
 
+/* ---- Bag-of-words transform (vocabulary tree) ----------------------------------------------------
+ * The tree of Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h (Node, :296-330) as arrays in node-id
+ * order, node 0 = root: parent[i] < i, the node's 32-byte descriptor, its weight (read at leaves).
+ * Children attach to their parent in id order and word ids number the leaves in id order, as
+ * loadFromTextFile (:1337-1420) and the tree builder do.  L = depth of the tree (m_L).  The arrays
+ * are copied to the device; host pointers. */
+typedef struct orbhip_vocabulary orbhip_vocabulary;
+int orbhip_vocabulary_create(orbhip_vocabulary** out, int device, int nnodes, const int32_t* parent, const uint8_t* desc,
+                             const double* weight, int L);
+void orbhip_vocabulary_destroy(orbhip_vocabulary* v);
+int orbhip_vocabulary_words(const orbhip_vocabulary* v);
+/* Replaces TemplatedVocabulary::transform(feature, word_id, weight, &nid, levelsup) (:1218-1259)
+ * for n descriptors (rows of 32 bytes): per descriptor the word id, the id of its ancestor at level
+ * L - levelsup (0 = root when that level is <= 0) and the word's weight.  The BowVector /
+ * FeatureVector of transform(features, v, fv, levelsup) (:1125-1194) are these triples accumulated
+ * in feature order (v.addWeight(word, weight) / fv.addFeature(node, i) for weight > 0).  Device
+ * pointers; asynchronous on the matcher's stream. */
+int orbhip_bow_transform_device(orbhip_matcher* m, const orbhip_vocabulary* v, const uint8_t* d_desc, int n, int levelsup,
+                                int32_t* d_word, int32_t* d_node, double* d_weight);
+
 /* Device self-tests of the arithmetic helpers (test instrumentation, host pointers, blocking):
  * which 0: n (y, x) float pairs -> n floats, the device's fastAtan2 in degrees
  *       1: n float angles (radians) -> n (cos, sin) float pairs as the descriptor kernel computes them

@@ -1,0 +1,231 @@
+// CPU ORACLE (test infrastructure only; never linked into or loaded by the product library).
+// PARITY UNPINNED: the reference ships no tests or fixtures for this path, cannot be built in this
+// image, and its vocabulary file is not part of the checkout; this restatement is pinned only by its
+// own known-answer tests on synthetic vocabulary trees.
+//
+// Literal restatement of the bag-of-words transform of the reference's vocabulary
+// (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h), as Frame::ComputeBoW / KeyFrame::ComputeBoW call
+// it (src/Frame.cc:281-288, src/KeyFrame.cc:82-91: transform(vCurrentDesc, mBowVec, mFeatVec, 4)):
+//   Node                               TemplatedVocabulary.h:296-330
+//   transform(feature, id, w, nid, levelsup)   :1218-1259
+//   transform(features, v, fv, levelsup)       :1125-1194
+//   FORB::distance                     Thirdparty/DBoW2/DBoW2/FORB.cpp:81-101
+//   BowVector::addWeight/addIfNotExist/normalize   BowVector.cpp:34-84
+//   FeatureVector::addFeature          FeatureVector.cpp:31-45
+//   L1Scoring::score                   ScoringObject.cpp:23-68
+#include "orb_ref.h"
+
+#include <cmath>
+#include <map>
+#include <vector>
+
+namespace {
+
+typedef unsigned int WordId;
+typedef double WordValue;
+typedef unsigned int NodeId;
+enum LNorm { L1, L2 };
+enum WeightingType { TF_IDF, TF, IDF, BINARY };
+
+struct Node {
+    NodeId id;
+    WordValue weight;
+    std::vector<NodeId> children;
+    NodeId parent;
+    const uint8_t* descriptor;
+    WordId word_id;
+    Node() : id(0), weight(0), parent(0), descriptor(nullptr), word_id(0) {}
+    bool isLeaf() const { return children.empty(); }
+};
+
+struct BowVector : std::map<WordId, WordValue> {
+    void addWeight(WordId id, WordValue v) {
+        iterator vit = this->lower_bound(id);
+        if (vit != this->end() && !(this->key_comp()(id, vit->first))) vit->second += v;
+        else this->insert(vit, value_type(id, v));
+    }
+    void addIfNotExist(WordId id, WordValue v) {
+        iterator vit = this->lower_bound(id);
+        if (vit == this->end() || (this->key_comp()(id, vit->first))) this->insert(vit, value_type(id, v));
+    }
+    void normalize(LNorm norm_type) {
+        double norm = 0.0;
+        if (norm_type == L1) {
+            for (iterator it = begin(); it != end(); ++it) norm += fabs(it->second);
+        } else {
+            for (iterator it = begin(); it != end(); ++it) norm += it->second * it->second;
+            norm = sqrt(norm);
+        }
+        if (norm > 0.0)
+            for (iterator it = begin(); it != end(); ++it) it->second /= norm;
+    }
+};
+
+struct FeatureVector : std::map<NodeId, std::vector<unsigned int> > {
+    void addFeature(NodeId id, unsigned int i_feature) {
+        iterator vit = this->lower_bound(id);
+        if (vit != this->end() && vit->first == id) vit->second.push_back(i_feature);
+        else {
+            vit = this->insert(vit, value_type(id, std::vector<unsigned int>()));
+            vit->second.push_back(i_feature);
+        }
+    }
+};
+
+}  // namespace
+
+struct orbref_vocabulary {
+    std::vector<Node> m_nodes;
+    int m_L;
+    WeightingType m_weighting;
+    bool must;   // m_scoring_object->mustNormalize(norm)
+    LNorm norm;
+
+    // TemplatedVocabulary.h:1218-1259
+    void transform(const uint8_t* feature, WordId& word_id, WordValue& weight, NodeId* nid, int levelsup) const {
+        std::vector<NodeId> nodes;
+        const int nid_level = m_L - levelsup;
+        if (nid_level <= 0 && nid != NULL) *nid = 0;  // root
+        NodeId final_id = 0;                          // root
+        int current_level = 0;
+        do {
+            ++current_level;
+            nodes = m_nodes[final_id].children;
+            final_id = nodes[0];
+            double best_d = orbref_hamming(feature, m_nodes[final_id].descriptor);
+            for (std::vector<NodeId>::const_iterator nit = nodes.begin() + 1; nit != nodes.end(); ++nit) {
+                NodeId id = *nit;
+                double d = orbref_hamming(feature, m_nodes[id].descriptor);
+                if (d < best_d) {
+                    best_d = d;
+                    final_id = id;
+                }
+            }
+            if (nid != NULL && current_level == nid_level) *nid = final_id;
+        } while (!m_nodes[final_id].isLeaf());
+        word_id = m_nodes[final_id].word_id;
+        weight = m_nodes[final_id].weight;
+    }
+
+    // TemplatedVocabulary.h:1125-1194
+    void transform(const uint8_t* features, int n, BowVector& v, FeatureVector& fv, int levelsup) const {
+        v.clear();
+        fv.clear();
+        if (m_nodes.size() <= 1) return;  // empty()
+        if (m_weighting == TF || m_weighting == TF_IDF) {
+            for (unsigned int i_feature = 0; i_feature < (unsigned)n; ++i_feature) {
+                WordId id;
+                NodeId nid;
+                WordValue w;
+                transform(features + (size_t)i_feature * 32, id, w, &nid, levelsup);
+                if (w > 0) {
+                    v.addWeight(id, w);
+                    fv.addFeature(nid, i_feature);
+                }
+            }
+            if (!v.empty() && !must) {
+                const double nd = v.size();
+                for (BowVector::iterator vit = v.begin(); vit != v.end(); vit++) vit->second /= nd;
+            }
+        } else {
+            for (unsigned int i_feature = 0; i_feature < (unsigned)n; ++i_feature) {
+                WordId id;
+                NodeId nid;
+                WordValue w;
+                transform(features + (size_t)i_feature * 32, id, w, &nid, levelsup);
+                if (w > 0) {
+                    v.addIfNotExist(id, w);
+                    fv.addFeature(nid, i_feature);
+                }
+            }
+        }
+        if (must) v.normalize(norm);
+    }
+};
+
+extern "C" {
+
+orbref_vocabulary* orbref_vocabulary_create(int nnodes, const int32_t* parent, const uint8_t* desc, const double* weight,
+                                            int L, int weighting, int scoring) {
+    if (nnodes < 1 || weighting < 0 || weighting > 3 || scoring < 0 || scoring > 5) return nullptr;
+    orbref_vocabulary* v = new orbref_vocabulary;
+    v->m_L = L;
+    v->m_weighting = (WeightingType)weighting;
+    // ScoringObject.h:72-87: every scoring normalises with L1 except L2_NORM (L2) and DOT_PRODUCT (none)
+    v->must = scoring != 5;
+    v->norm = scoring == 1 ? L2 : L1;
+    v->m_nodes.resize(nnodes);
+    // nodes arrive in id order and attach to their parent in that order (loadFromTextFile :1380-1415)
+    for (int nid = 0; nid < nnodes; nid++) {
+        Node& nd = v->m_nodes[nid];
+        nd.id = nid;
+        nd.descriptor = desc + (size_t)nid * 32;
+        nd.weight = weight[nid];
+        if (nid > 0) {
+            nd.parent = parent[nid];
+            v->m_nodes[parent[nid]].children.push_back(nid);
+        }
+    }
+    WordId wid = 0;
+    for (int nid = 1; nid < nnodes; nid++)
+        if (v->m_nodes[nid].isLeaf()) v->m_nodes[nid].word_id = wid++;
+    return v;
+}
+
+void orbref_vocabulary_destroy(orbref_vocabulary* v) { delete v; }
+
+void orbref_bow_transform_feature(const orbref_vocabulary* v, const uint8_t* feature, int levelsup, int32_t* word,
+                                  int32_t* node, double* weight) {
+    WordId id;
+    NodeId nid;
+    WordValue w;
+    v->transform(feature, id, w, &nid, levelsup);
+    *word = (int32_t)id;
+    *node = (int32_t)nid;
+    *weight = w;
+}
+
+int orbref_bow_transform(const orbref_vocabulary* v, const uint8_t* features, int n, int levelsup, int32_t* bow_words,
+                         double* bow_values, int32_t* n_words, int32_t* fv_nodes, int32_t* fv_start, int32_t* fv_features,
+                         int32_t* n_nodes) {
+    BowVector bv;
+    FeatureVector fv;
+    v->transform(features, n, bv, fv, levelsup);
+    int i = 0;
+    for (BowVector::const_iterator it = bv.begin(); it != bv.end(); ++it, ++i) {
+        bow_words[i] = (int32_t)it->first;
+        bow_values[i] = it->second;
+    }
+    *n_words = i;
+    int k = 0, o = 0;
+    for (FeatureVector::const_iterator it = fv.begin(); it != fv.end(); ++it, ++k) {
+        fv_nodes[k] = (int32_t)it->first;
+        fv_start[k] = o;
+        for (size_t j = 0; j < it->second.size(); j++) fv_features[o++] = (int32_t)it->second[j];
+    }
+    fv_start[k] = o;
+    *n_nodes = k;
+    return 0;
+}
+
+// L1Scoring::score (ScoringObject.cpp:23-68) on two sorted (word, value) lists.
+double orbref_bow_score_l1(const int32_t* w1, const double* v1, int n1, const int32_t* w2, const double* v2, int n2) {
+    int i = 0, j = 0;
+    double score = 0;
+    while (i < n1 && j < n2) {
+        const double vi = v1[i], wi = v2[j];
+        if (w1[i] == w2[j]) {
+            score += fabs(vi - wi) - fabs(vi) - fabs(wi);
+            ++i;
+            ++j;
+        } else if (w1[i] < w2[j]) {
+            while (i < n1 && w1[i] < w2[j]) ++i;  // lower_bound
+        } else {
+            while (j < n2 && w2[j] < w1[i]) ++j;
+        }
+    }
+    score = -score / 2.0;
+    return score;
+}
+
+}  // extern "C"

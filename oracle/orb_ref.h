@@ -123,6 +123,25 @@ int orbref_window_search(const void* kp1, const uint8_t* desc1, int n1, const ui
  * least median distance to the others (first one on ties), its median in *best_median. */
 int orbref_distinctive_descriptor(const uint8_t* desc, int n, int32_t* best_median);
 
+/* ---- Bag-of-words transform of the vocabulary tree (oracle/bow_ref.cpp) -------------------------
+ * Tree given as nnodes nodes in id order (node 0 = root): parent[i], descriptor (32 B), weight
+ * (used at leaves).  Children attach in id order; word ids count the leaves in id order.
+ * weighting: 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY; scoring: 0 L1_NORM .. 5 DOT_PRODUCT (BowVector.h:36-53). */
+typedef struct orbref_vocabulary orbref_vocabulary;
+orbref_vocabulary* orbref_vocabulary_create(int nnodes, const int32_t* parent, const uint8_t* desc, const double* weight,
+                                            int L, int weighting, int scoring);
+void orbref_vocabulary_destroy(orbref_vocabulary* v);
+/* transform(feature, word_id, weight, &nid, levelsup) (TemplatedVocabulary.h:1218-1259). */
+void orbref_bow_transform_feature(const orbref_vocabulary* v, const uint8_t* feature, int levelsup, int32_t* word,
+                                  int32_t* node, double* weight);
+/* transform(features, BowVector, FeatureVector, levelsup) (:1125-1194): the BowVector as sorted
+ * (word, value) pairs, the FeatureVector as sorted nodes with CSR lists of feature indices. */
+int orbref_bow_transform(const orbref_vocabulary* v, const uint8_t* features, int n, int levelsup, int32_t* bow_words,
+                         double* bow_values, int32_t* n_words, int32_t* fv_nodes, int32_t* fv_start, int32_t* fv_features,
+                         int32_t* n_nodes);
+/* L1Scoring::score (ScoringObject.cpp:23-68). */
+double orbref_bow_score_l1(const int32_t* w1, const double* v1, int n1, const int32_t* w2, const double* v2, int n2);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,7 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("orb_ref.cpp", "frame_ref.cpp", "orb_ref.h")]
+    src = [os.path.join(_HERE, f) for f in ("orb_ref.cpp", "frame_ref.cpp", "bow_ref.cpp", "orb_ref.h")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
         subprocess.check_call(["make", "-C", _HERE, "liborbref.so"])
     return _SO
@@ -74,6 +74,15 @@ def lib():
         L.orbref_frame_grid.argtypes = [vp, i32, vp, vp, vp]
         L.orbref_features_in_area.argtypes = [vp, i32, vp, f32, f32, f32, i32, i32, vp, i32]
         L.orbref_search_for_initialization.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, i32, f32, i32, vp]
+        L.orbref_vocabulary_create.restype = vp
+        L.orbref_vocabulary_create.argtypes = [i32, vp, vp, vp, i32, i32, i32]
+        L.orbref_vocabulary_destroy.argtypes = [vp]
+        L.orbref_vocabulary_destroy.restype = None
+        L.orbref_bow_transform_feature.argtypes = [vp, vp, i32, vp, vp, vp]
+        L.orbref_bow_transform_feature.restype = None
+        L.orbref_bow_transform.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+        L.orbref_bow_score_l1.restype = C.c_double
+        L.orbref_bow_score_l1.argtypes = [vp, vp, i32, vp, vp, i32]
         L.orbref_distinctive_descriptor.argtypes = [vp, i32, vp]
         L.orbref_window_search.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, f32, i32, vp]
         _lib = L
@@ -243,3 +252,54 @@ def distinctive_descriptor(desc):
     med = C.c_int32(0)
     idx = lib().orbref_distinctive_descriptor(_p(desc), len(desc), C.byref(med))
     return idx, med.value
+
+
+# ---- Bag-of-words transform (oracle/bow_ref.cpp) --------------------------------------------------
+class RefVocabulary:
+    """The vocabulary tree of Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h over the oracle.
+    parent[nnodes] (node 0 = root), desc[nnodes, 32], weight[nnodes] (float64)."""
+
+    def __init__(self, parent, desc, weight, L, weighting=0, scoring=0):
+        self.parent = np.ascontiguousarray(parent, dtype=np.int32)
+        self.desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 32)
+        self.weight = np.ascontiguousarray(weight, dtype=np.float64)
+        self.L = L
+        self._h = lib().orbref_vocabulary_create(len(self.parent), _p(self.parent), _p(self.desc), _p(self.weight), L,
+                                                 weighting, scoring)
+        if not self._h:
+            raise ValueError("bad vocabulary")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orbref_vocabulary_destroy(self._h)
+            self._h = None
+
+    def transform_features(self, features, levelsup=4):
+        """Per feature: (word id, node id at level L - levelsup, weight)."""
+        f = np.ascontiguousarray(features, dtype=np.uint8).reshape(-1, 32)
+        word = np.zeros(len(f), np.int32)
+        node = np.zeros(len(f), np.int32)
+        w = np.zeros(len(f), np.float64)
+        wi, ni, we = C.c_int32(), C.c_int32(), C.c_double()
+        for i in range(len(f)):
+            lib().orbref_bow_transform_feature(self._h, _p(f[i]), levelsup, C.byref(wi), C.byref(ni), C.byref(we))
+            word[i], node[i], w[i] = wi.value, ni.value, we.value
+        return word, node, w
+
+    def transform(self, features, levelsup=4):
+        """(BowVector as (words, values), FeatureVector as (nodes, start, feature indices))."""
+        f = np.ascontiguousarray(features, dtype=np.uint8).reshape(-1, 32)
+        n = len(f)
+        bw, bv = np.zeros(n + 1, np.int32), np.zeros(n + 1, np.float64)
+        fn, fs, ff = np.zeros(n + 1, np.int32), np.zeros(n + 2, np.int32), np.zeros(n + 1, np.int32)
+        nw, nn = C.c_int32(), C.c_int32()
+        lib().orbref_bow_transform(self._h, _p(f), n, levelsup, _p(bw), _p(bv), C.byref(nw), _p(fn), _p(fs), _p(ff),
+                                   C.byref(nn))
+        return (bw[:nw.value].copy(), bv[:nw.value].copy()), (fn[:nn.value].copy(), fs[:nn.value + 1].copy(),
+                                                                ff[:fs[nn.value]].copy())
+
+
+def bow_score_l1(a, b):
+    w1, v1 = np.ascontiguousarray(a[0], np.int32), np.ascontiguousarray(a[1], np.float64)
+    w2, v2 = np.ascontiguousarray(b[0], np.int32), np.ascontiguousarray(b[1], np.float64)
+    return lib().orbref_bow_score_l1(_p(w1), _p(v1), len(w1), _p(w2), _p(v2), len(w2))

@@ -4,3 +4,4 @@ from ._lib import OrbhipError  # noqa: F401
 from .extractor import KP_DTYPE, ORBextractor  # noqa: F401
 from .frame import AREA_QUERY_DTYPE, FrameBatch  # noqa: F401
 from .matcher import ORBmatcher  # noqa: F401
+from .vocabulary import ORBVocabulary  # noqa: F401

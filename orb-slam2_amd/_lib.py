@@ -95,6 +95,11 @@ def lib():
                                                           vp, i32, f32, i32, vp, vp]
     L.orbhip_search_for_initialization.argtypes = [vp, vp, vp, i32, vp, vp, i32, OrbFrameBounds, vp, i32, f32, i32, vp, vp]
     L.orbhip_window_search.argtypes = [vp, vp, vp, i32, vp, vp, vp, i32, OrbFrameBounds, i32, i32, i32, f32, i32, vp, vp]
+    L.orbhip_vocabulary_create.argtypes = [C.POINTER(vp), i32, i32, vp, vp, vp, i32]
+    L.orbhip_vocabulary_destroy.argtypes = [vp]
+    L.orbhip_vocabulary_destroy.restype = None
+    L.orbhip_vocabulary_words.argtypes = [vp]
+    L.orbhip_bow_transform_device.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
     L.orbhip_distinctive_descriptors_device.argtypes = [vp, vp, vp, i32, vp, vp]
     L.orbhip_window_search_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, OrbFrameBounds,
                                               i32, i32, i32, f32, i32, vp, vp]

@@ -65,3 +65,39 @@ def synth_descriptors(nq, nt, seed=0):
             for b in bits:
                 query[qi[k], b >> 3] ^= np.uint8(1 << (b & 7))
     return query, train
+
+
+def synth_vocabulary(k, L, seed=0, tie_share=0.15, stop_share=0.05):
+    """A synthetic vocabulary tree with branching factor k and depth L, nodes numbered the way the
+    reference builds and stores them (a node's children are consecutive and follow it), random 256-bit
+    node descriptors, idf-like leaf weights.  A share of sibling groups repeat a descriptor (distance
+    ties -> the first child wins) and a share of words are stopped (weight 0).
+    Returns (parent int32[n], desc uint8[n, 32], weight float64[n])."""
+    rng = np.random.default_rng(seed)
+    parent, depth = [0], [0]
+    stack = [0]
+    while stack:  # depth-first creation, children of a node created together (HKmeansStep)
+        p = stack.pop()
+        if depth[p] == L:
+            continue
+        kids = []
+        for _ in range(k):
+            parent.append(p)
+            depth.append(depth[p] + 1)
+            kids.append(len(parent) - 1)
+        stack.extend(reversed(kids))
+    n = len(parent)
+    parent = np.array(parent, np.int32)
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    # children resemble their parent a little, as in a k-means tree
+    for i in range(1, n):
+        keep = rng.integers(0, 256, 32, dtype=np.uint8) & rng.integers(0, 256, 32, dtype=np.uint8)
+        desc[i] = (desc[parent[i]] & ~keep) | (desc[i] & keep)
+    for i in range(2, n):
+        if parent[i] == parent[i - 1] and rng.random() < tie_share:
+            desc[i] = desc[i - 1]
+    weight = np.zeros(n, np.float64)
+    leaf = np.array(depth) == L
+    weight[leaf] = rng.uniform(0.5, 9.0, int(leaf.sum()))
+    weight[leaf & (rng.random(n) < stop_share)] = 0.0
+    return parent, desc, weight

@@ -136,3 +136,27 @@ def test_distinctive_descriptor_median_rank_and_first_minimum(orbref):
     assert orbref.distinctive_descriptor(d[:1]) == (0, 0)
     assert orbref.distinctive_descriptor(d[:2]) == (0, 0)  # N = 2: rank 0 is the diagonal
     assert orbref.distinctive_descriptor(d[:0]) == (-1, INT_MAX)
+
+
+def test_bow_transform_by_hand(orbref):
+    """Depth-2 binary tree: root 0 -> {1, 4}; 1 -> {2, 3}; 4 -> {5, 6}.  Words (leaves in id order):
+    2 -> 0, 3 -> 1, 5 -> 2, 6 -> 3."""
+    parent = np.array([0, 0, 1, 1, 0, 4, 4], np.int32)
+    desc = np.stack([bits(0), bits(0), bits(0), bits(8), bits(200), bits(200), bits(200)])
+    weight = np.array([0, 0, 1.5, 2.0, 0, 0.0, 4.0])
+    voc = orbref.RefVocabulary(parent, desc, weight, 2)
+    # bits(3): nearer to node 1 (3) than node 4 (197); then node 2 (3) vs node 3 (5) -> word 0
+    # bits(5): node 2 (5) vs node 3 (3) -> word 1; bits(4): tie 4 / 4 -> first child, word 0
+    # bits(150): node 4; children 5 and 6 identical -> first (word 2, stopped: weight 0)
+    f = np.stack([bits(3), bits(5), bits(4), bits(150)])
+    word, node, w = voc.transform_features(f, 1)  # node at level L - 1 = 1
+    assert list(word) == [0, 1, 0, 2] and list(node) == [1, 1, 1, 4] and list(w) == [1.5, 2.0, 1.5, 0.0]
+    assert list(voc.transform_features(f, 2)[1]) == [0, 0, 0, 0]   # level 0 = root
+    assert list(voc.transform_features(f, 0)[1]) == [2, 3, 2, 5]   # level L = the leaves
+    (bw, bv), (fn, fs, ff) = voc.transform(f, 1)
+    # TF_IDF + L1: word 0 = 1.5 + 1.5, word 1 = 2.0, stopped word absent; normalised by 5.0
+    assert list(bw) == [0, 1] and list(bv) == [3.0 / 5.0, 2.0 / 5.0]
+    assert list(fn) == [1] and list(ff) == [0, 1, 2]
+    binary = orbref.RefVocabulary(parent, desc, weight, 2, weighting=3, scoring=5)
+    (bw, bv), _ = binary.transform(f, 1)
+    assert list(bw) == [0, 1] and list(bv) == [1.5, 2.0]           # addIfNotExist, no normalisation
