@@ -342,7 +342,41 @@ def extra_legs(orb, torch, dev, threads):
                                                                     and np.array_equal(oo2[2], r_d2))}
     del q2, t2
     res["windowed_matchers"] = windowed_leg(orb, torch, dev, orbref)
+    res["bow_transform"] = bow_leg(orb, torch, dev, orbref, m)
     return res
+
+
+def bow_leg(orb, torch, dev, orbref, m):
+    """Vocabulary descent of 256 x 2000 descriptors through a synthetic k = 10, L = 5 tree (111 k nodes),
+    next to the oracle on one thread for 2000 descriptors."""
+    k, L, n = 10, 5, 256 * 2000
+    parent, desc, weight = orb.synth.synth_vocabulary(k, L, seed=1, tie_share=0.05)
+    voc = orb.ORBVocabulary(parent, desc, weight, L, device=dev)
+    cuda = "cuda:%d" % dev
+    rng = np.random.default_rng(2)
+    f = desc[rng.integers(1, len(desc), n)] ^ (rng.integers(0, 256, (n, 32), dtype=np.uint8)
+                                                & rng.integers(0, 256, (n, 32), dtype=np.uint8)
+                                                & rng.integers(0, 256, (n, 32), dtype=np.uint8))
+    d_f = torch.from_numpy(f).to(cuda)
+    word = torch.empty(n, dtype=torch.int32, device=cuda)
+    node = torch.empty(n, dtype=torch.int32, device=cuda)
+    wgt = torch.empty(n, dtype=torch.float64, device=cuda)
+    torch.cuda.synchronize(dev)
+    ts = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        voc.transform_device(m, d_f.data_ptr(), n, 4, word.data_ptr(), node.data_ptr(), wgt.data_ptr())
+        m.synchronize()
+        ts.append(time.perf_counter() - t0)
+    best = float(np.median(ts[1:]))
+    ref = orbref.RefVocabulary(parent, desc, weight, L)
+    t0 = time.perf_counter()
+    rword, rnode, _ = ref.transform_features(f[:2000], 4)
+    cdt = time.perf_counter() - t0
+    ok = np.array_equal(word[:2000].cpu().numpy(), rword) and np.array_equal(node[:2000].cpu().numpy(), rnode)
+    return {"descriptors": n, "tree": "k=%d L=%d (%d nodes, synthetic)" % (k, L, len(parent)), "ms": round(best * 1e3, 3),
+            "descriptors_per_sec": float("%.4g" % (n / best)),
+            "cpu_oracle_1_thread_descriptors_per_sec": float("%.4g" % (2000 / cdt)), "parity_first_2000": bool(ok)}
 
 
 def windowed_leg(orb, torch, dev, orbref):
