@@ -45,6 +45,17 @@ __device__ __forceinline__ uint32_t as_u32(short2v v) { return __builtin_bit_cas
 // (byte lo | byte hi << 16) of two source bytes; selector bytes 0-3 pick from b, 4-7 from a, 0x0c = 0
 #define PAIR(a, b, sel) as_s2(__builtin_amdgcn_perm((a), (b), (sel)))
 
+// Inclusive prefix sum over the 64 lanes with DPP row shifts and broadcasts (no LDS).
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2, 3
+    return v;
+}
+
 // maximum of the 8 neighbours of the score byte at p (score tile has a zero border)
 __device__ __forceinline__ uint32_t nb_max8(const uint8_t* __restrict__ p, int sp) {
     const uint32_t a = max(max((uint32_t)p[-sp - 1], (uint32_t)p[-sp]), (uint32_t)p[-sp + 1]);
@@ -175,24 +186,22 @@ __global__ __launch_bounds__(FC_THREADS) void k_fast_cell(const uint8_t* __restr
         // per-lane pass nibbles (bit j = pixel j of the group passes and is an examined pixel)
         const uint32_t nibA = ~(((za0 >> 15) & 1u) | ((za0 >> 30) & 2u) | ((za1 >> 13) & 4u) | ((za1 >> 28) & 8u)) & vnib;
         const uint32_t nibB = ~(((zb0 >> 15) & 1u) | ((zb0 >> 30) & 2u) | ((zb1 >> 13) & 4u) | ((zb1 >> 28) & 8u)) & vnib;
-        int beforeA = 0, beforeB = 0, totA = 0, totB = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const unsigned long long ma = __ballot((nibA >> j) & 1u), mb = __ballot((nibB >> j) & 1u);
-            beforeA += lane_prefix(ma);
-            beforeB += lane_prefix(mb);
-            totA += __popcll(ma);
-            totB += __popcll(mb);
-        }
+        // every lane appends its own survivors as one run per row: positions from one wave-wide prefix
+        // sum of the per-lane counts (both rows packed in one register); each row stays in raster order
+        const uint32_t cnt = (uint32_t)__popc(nibA) | ((uint32_t)__popc(nibB) << 16);
+        const uint32_t incl = wave_inclusive_sum(cnt);
+        const uint32_t excl = incl - cnt;
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const int totA = (int)(tot & 0xffffu), totB = (int)(tot >> 16);
         {
-            int pos = n + beforeA;
+            int pos = n + (int)(excl & 0xffffu);
             const uint32_t e = (uint32_t)(ra << 8) | (uint32_t)(4 * gg);
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 if ((nibA >> j) & 1u) wl[pos++] = (uint16_t)(e + j);
         }
         {
-            int pos = n + totA + beforeB;
+            int pos = n + totA + (int)(excl >> 16);
             const uint32_t e = (uint32_t)(rb2 << 8) | (uint32_t)(4 * gg);
 #pragma unroll
             for (int j = 0; j < 4; j++)
