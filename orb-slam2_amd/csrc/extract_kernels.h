@@ -31,8 +31,10 @@ void launch_blur(hipStream_t st, const GeomDev& hg, int batch, int level, const 
 // lvl_list holds key_words (1 or 2) 32-bit words per keypoint, low word first.
 void launch_orient_describe(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* pyr, const uint8_t* blur,
                             const GeomDev* dg, const uint32_t* lvl_list, int key_words, const int* lvl_count,
-                            const uint32_t* otab, float* angles, const int8_t* pattern, OrbKeypointDev* kp_out,
-                            uint8_t* desc_out, int* n_out, int cap);
+                            const uint32_t* otab, float* angles, const int8_t* pattern, void* slot_recs,
+                            OrbKeypointDev* kp_out, uint8_t* desc_out, int* n_out, int cap);
+// slot_recs: scratch of nfeatures * slot_record_bytes() per frame
+size_t slot_record_bytes();
 // HARRIS_SCORE: Harris responses of the FAST candidates into 64-bit keys, then the selection on those.
 void launch_harris_select(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* pyr, const GeomDev* dg,
                           const CellDesc* cells, const uint32_t* cand, uint64_t* cand64, const int* n_total, int* n_retain,

@@ -761,6 +761,52 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
 }
 
 // ---------------------------------------------------------------------------------------------
+// Per output slot, everything the descriptor kernel needs to start loading pixels: resolving a slot
+// to its level, key and plane takes a chain of dependent small loads, which is cheap with one lane
+// per slot here and expensive with a whole lane group waiting on it there.
+struct SlotRec {
+    long long pix;   // byte offset of the keypoint's pixel inside the pyramid / blur arena
+    uint32_t key;    // score << 24 | y << 12 | x (level coordinates)
+    uint32_t hi;     // HARRIS_SCORE: ordered response bits
+    int level_oi;    // level << 24 | output index
+    float scale;     // mvScaleFactor[level]
+    float kp_size;
+    int valid;
+};
+
+__global__ __launch_bounds__(256) void k_slots(const GeomDev* __restrict__ g, const uint32_t* __restrict__ lvl_list,
+                                               int key_words, const int* __restrict__ lvl_count, SlotRec* __restrict__ recs,
+                                               int* __restrict__ n_out) {
+    const int f = blockIdx.y;
+    const int slot = blockIdx.x * 256 + threadIdx.x;
+    if (slot == 0) {
+        int n = 0;
+        for (int l = 0; l < g->nlevels; l++) n += lvl_count[f * g->nlevels + l];
+        n_out[f] = n;
+    }
+    if (slot >= g->nfeatures) return;
+    SlotRec r;
+    r.valid = 0;
+    r.pix = 0;
+    r.key = r.hi = 0;
+    r.level_oi = 0;
+    r.scale = r.kp_size = 0.f;
+    int level, k, oi;
+    uint32_t key, hi;
+    if (slot_to_key(g, lvl_list, key_words, lvl_count, f, slot, level, k, key, hi, oi)) {
+        const LevelGeom& L = g->lv[level];
+        const int x = key & 0xfff, y = (key >> 12) & 0xfff;
+        r.pix = (long long)f * g->frame_bytes + L.plane_off + (long long)(y + ORB_EDGE) * L.stride + (x + ORB_EDGE);
+        r.key = key;
+        r.hi = hi;
+        r.level_oi = (level << 24) | oi;
+        r.scale = L.scale;
+        r.kp_size = L.kp_size;
+        r.valid = 1 + L.stride;  // non-zero; carries the plane's row stride
+    }
+    recs[(long long)f * g->nfeatures + slot] = r;
+}
+
 // IC_Angle (src/ORBextractor.cc:124-151) + computeOrbDescriptor (:154-194) + the output record of
 // operator() (:769-777) in one kernel, OD_LPK lanes per keypoint, so that the chain of
 // dependent memory round trips (level counts -> key -> pixels) is paid once per keypoint.
@@ -784,36 +830,41 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
 // lanes per keypoint mean less redundant arithmetic per wave; 16 keeps the loads of one keypoint
 // row-contiguous (each lane then produces 2 descriptor bytes).
 #define OD_LPK 32
-#define OD_KPB (256 / OD_LPK)  // keypoints per workgroup
+#define OD_KPB (256 / OD_LPK)  // keypoints per workgroup and round
+#define OD_ROUNDS 1
 #define OD_BYTES (32 / OD_LPK)  // descriptor bytes per lane
 #define DS_ITERS ((DS_ROWS * DS_DWORDS + OD_LPK - 1) / OD_LPK)
 #define OR_ITERS ((31 * 8 + OD_LPK - 1) / OD_LPK)
 
 __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
                                                          const GeomDev* __restrict__ g,
-                                                         const uint32_t* __restrict__ lvl_list, int key_words,
-                                                         const int* __restrict__ lvl_count,
+                                                         const SlotRec* __restrict__ recs, int key_words,
                                                          const uint32_t* __restrict__ otab, float* __restrict__ angles,
                                                          const int8_t* __restrict__ pattern,
                                                          OrbKeypointDev* __restrict__ kp_out, uint8_t* __restrict__ desc_out,
-                                                         int* __restrict__ n_out, int cap) {
+                                                         int cap) {
     __shared__ uint32_t ds_win[OD_KPB][DS_ROWS * DS_DWORDS];
+    // the disc weight table and the test pattern are the same for every keypoint: one copy per
+    // workgroup in LDS instead of a trip through the vector cache per keypoint
+    __shared__ uint2 s_otab[31 * 8];
+    __shared__ uint4 s_pat[64];
+    if (threadIdx.x < 31 * 8) s_otab[threadIdx.x] = ((const uint2*)otab)[threadIdx.x];
+    if (threadIdx.x < 64) s_pat[threadIdx.x] = ((const uint4*)pattern)[threadIdx.x];
+    __syncthreads();
     int bx = blockIdx.x, f = blockIdx.y;
     xcd_frame_swizzle(bx, f, (int)gridDim.x, (int)gridDim.y);
-    const int slot = bx * OD_KPB + (threadIdx.x / OD_LPK);
     const int li = threadIdx.x % OD_LPK;
-    if (slot == 0 && li == 0) {
-        int n = 0;
-        for (int l = 0; l < g->nlevels; l++) n += lvl_count[f * g->nlevels + l];
-        n_out[f] = n;
-    }
-    int level, k, oi;
-    uint32_t key, hi;
-    if (!slot_to_key(g, lvl_list, key_words, lvl_count, f, slot, level, k, key, hi, oi)) return;
-    const LevelGeom& L = g->lv[level];
+    // OD_ROUNDS keypoints per lane group, one after the other: fewer, longer-lived waves
+    for (int round = 0; round < OD_ROUNDS; round++) {
+    const int slot = (bx * OD_ROUNDS + round) * OD_KPB + (threadIdx.x / OD_LPK);
+    if (slot >= g->nfeatures) continue;
+    const SlotRec rec = recs[(long long)f * g->nfeatures + slot];
+    if (!rec.valid) continue;
+    const uint32_t key = rec.key, hi = rec.hi;
+    const int level = rec.level_oi >> 24, oi = rec.level_oi & 0xffffff;
     const int x = key & 0xfff, y = (key >> 12) & 0xfff;
-    const int stride = L.stride;
-    const long long pix = (long long)f * g->frame_bytes + L.plane_off + (long long)(y + ORB_EDGE) * stride + (x + ORB_EDGE);
+    const int stride = rec.valid - 1;
+    const long long pix = rec.pix;
 
     // all loads of both windows are issued before anything waits on them
     const uint8_t* ocenter = pyr + pix;
@@ -840,7 +891,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
         const int idx = it * OD_LPK + li;
         if (idx < 31 * 8) {
             const int v = (idx >> 3) - ORB_HALF_PATCH;
-            const uint2 w = ((const uint2*)otab)[idx];
+            const uint2 w = s_otab[idx];
             const int s = (int)__builtin_amdgcn_udot4(disc[it], w.y, 0u, false);
             const int t = (int)__builtin_amdgcn_udot4(disc[it], w.x, 0u, false);
             m10 += t - 16 * s;
@@ -867,7 +918,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
     const float angle = angle_deg * factorPI;
     const float a = orbtrig::cos_f<false>(angle), b = orbtrig::sin_f<false>(angle);
     const uint8_t* center = (const uint8_t*)win + DS_REACH * (4 * DS_DWORDS) + DS_REACH + lead;
-    const int8_t* pat = pattern + li * (32 * OD_BYTES);
+    const int8_t* pat = (const int8_t*)s_pat + li * (32 * OD_BYTES);
     uint32_t val = 0;
 #pragma unroll
     for (int j = 0; j < 8 * OD_BYTES; j++) {
@@ -879,18 +930,19 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
         const int v0 = center[r0 * (4 * DS_DWORDS) + c0], v1 = center[r1 * (4 * DS_DWORDS) + c1];
         val |= (uint32_t)(v0 < v1) << j;
     }
-    if (oi >= cap) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // window reads done before the next round overwrites it
+    if (oi >= cap) continue;
     const long long o = (long long)f * cap + oi;
     if (OD_BYTES == 1) desc_out[o * 32 + li] = (uint8_t)val;
     else if (OD_BYTES == 2) ((uint16_t*)(desc_out + o * 32))[li] = (uint16_t)val;
     else ((uint32_t*)(desc_out + o * 32))[li] = val;
     if (li < 7) {
         uint32_t w;
-        const float scale = L.scale;
+        const float scale = rec.scale;
         switch (li) {
             case 0: w = __float_as_uint(level ? __fmul_rn((float)x, scale) : (float)x); break;
             case 1: w = __float_as_uint(level ? __fmul_rn((float)y, scale) : (float)y); break;
-            case 2: w = __float_as_uint(L.kp_size); break;
+            case 2: w = __float_as_uint(rec.kp_size); break;
             case 3: w = __float_as_uint(angle_deg); break;
             case 4: w = key_words == 2 ? __float_as_uint(ordered_to_float(hi)) : __float_as_uint((float)(key >> 24)); break;
             case 5: w = (uint32_t)level; break;
@@ -898,6 +950,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
         }
         ((uint32_t*)(kp_out + o))[li] = w;
     }
+    }  // round
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1003,12 +1056,16 @@ void launch_blur(hipStream_t st, const GeomDev& hg, int batch, int level, const 
 
 void launch_orient_describe(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* pyr, const uint8_t* blur,
                             const GeomDev* dg, const uint32_t* lvl_list, int key_words, const int* lvl_count,
-                            const uint32_t* otab, float* angles, const int8_t* pattern, OrbKeypointDev* kp_out,
-                            uint8_t* desc_out, int* n_out, int cap) {
-    dim3 grid((hg.nfeatures + OD_KPB - 1) / OD_KPB, batch), block(256);
-    hipLaunchKernelGGL(k_orient_describe, grid, block, 0, st, pyr, blur, dg, lvl_list, key_words, lvl_count, otab, angles,
-                       pattern, kp_out, desc_out, n_out, cap);
+                            const uint32_t* otab, float* angles, const int8_t* pattern, void* slot_recs,
+                            OrbKeypointDev* kp_out, uint8_t* desc_out, int* n_out, int cap) {
+    hipLaunchKernelGGL(k_slots, dim3((hg.nfeatures + 255) / 256, batch), dim3(256), 0, st, dg, lvl_list, key_words, lvl_count,
+                       (SlotRec*)slot_recs, n_out);
+    dim3 grid((hg.nfeatures + OD_KPB * OD_ROUNDS - 1) / (OD_KPB * OD_ROUNDS), batch), block(256);
+    hipLaunchKernelGGL(k_orient_describe, grid, block, 0, st, pyr, blur, dg, (const SlotRec*)slot_recs, key_words, otab, angles,
+                       pattern, kp_out, desc_out, cap);
 }
+
+size_t slot_record_bytes() { return sizeof(SlotRec); }
 
 void launch_test_atan2(hipStream_t st, const float* yx, float* out, int n) {
     hipLaunchKernelGGL(k_test_atan2, dim3((n + 255) / 256), dim3(256), 0, st, yx, out, n);

@@ -86,7 +86,7 @@ struct orbhip_extractor {
     int last_batch = 0;  // frames of the last chunk (for the stage taps)
 
     DeviceBuf d_geom, d_cells, d_xofs, d_xab, d_ysrc, d_yab, d_disc, d_pattern;
-    DeviceBuf d_pyr, d_blur, d_score, d_cand, d_cand64, d_ntotal, d_nretain, d_lvl, d_lvlcount, d_angles, d_err;
+    DeviceBuf d_pyr, d_blur, d_score, d_cand, d_cand64, d_ntotal, d_nretain, d_lvl, d_lvlcount, d_angles, d_slots, d_err;
     DeviceBuf d_img, d_kp, d_desc, d_n;  // staging of the host-pointer entry points
 };
 
@@ -319,6 +319,7 @@ int set_size(orbhip_extractor* e, int rows, int cols, int batch) {
     if ((rc = e->d_lvl.ensure(std::max<size_t>(B * g.lvl_per_frame * key_bytes, 16)))) return rc;
     if ((rc = e->d_lvlcount.ensure(B * g.nlevels * 4))) return rc;
     if ((rc = e->d_angles.ensure(B * g.nfeatures * 4))) return rc;
+    if ((rc = e->d_slots.ensure(B * g.nfeatures * orbk::slot_record_bytes()))) return rc;
     return ORBHIP_OK;
 }
 
@@ -378,7 +379,8 @@ int run_chunk(orbhip_extractor* e, hipStream_t st, int slot0, const uint8_t* d_i
     for (int l = 0; l < g.nlevels; l++) orbk::launch_blur(st, g, batch, l, pyr, blur, dg, e->gtaps);
     STAGE_MARK(7);
     orbk::launch_orient_describe(st, g, batch, pyr, blur, dg, lvl, key_words, lvlcount, e->d_disc.as<uint32_t>(), angles,
-                                 e->d_pattern.as<int8_t>(), (OrbKeypointDev*)d_kp, d_desc, d_n, cap);
+                                 e->d_pattern.as<int8_t>(), e->d_slots.as<uint8_t>() + (size_t)slot0 * g.nfeatures * orbk::slot_record_bytes(),
+                                 (OrbKeypointDev*)d_kp, d_desc, d_n, cap);
     STAGE_MARK(8);
 #undef STAGE_MARK
     HIPCHK(hipGetLastError());
@@ -499,7 +501,7 @@ void orbhip_extractor_destroy(orbhip_extractor* e) {
     if (e->stream) hipStreamSynchronize(e->stream);
     DeviceBuf* bufs[] = {&e->d_geom, &e->d_cells, &e->d_xofs, &e->d_xab, &e->d_ysrc, &e->d_yab, &e->d_disc, &e->d_pattern,
                          &e->d_pyr, &e->d_blur, &e->d_score, &e->d_cand, &e->d_cand64, &e->d_ntotal, &e->d_nretain, &e->d_lvl,
-                         &e->d_lvlcount, &e->d_angles, &e->d_err, &e->d_img, &e->d_kp, &e->d_desc, &e->d_n};
+                         &e->d_lvlcount, &e->d_angles, &e->d_slots, &e->d_err, &e->d_img, &e->d_kp, &e->d_desc, &e->d_n};
     for (DeviceBuf* b : bufs) b->release();
     for (hipEvent_t ev : e->prof_ev) hipEventDestroy(ev);
     for (hipEvent_t ev : e->worker_done) hipEventDestroy(ev);
@@ -578,7 +580,7 @@ int orbhip_extractor_synchronize(orbhip_extractor* e) {
     }
     if (e->profiling) {
         const int nl = e->nlevels;
-        const int per_chunk[ORB_NSTAGES] = {1, nl - 1, e->fused_fast ? 0 : nl, 1, e->scoreType == ORBHIP_HARRIS_SCORE ? 4 : 3, 0, nl, 1};
+        const int per_chunk[ORB_NSTAGES] = {1, nl - 1, e->fused_fast ? 0 : nl, 1, e->scoreType == ORBHIP_HARRIS_SCORE ? 4 : 3, 0, nl, 2};
         for (int s = 0; s < ORB_NSTAGES; s++) {
             e->stage_ms[s] = 0.f;
             e->stage_launches[s] = per_chunk[s] * e->prof_chunks;
