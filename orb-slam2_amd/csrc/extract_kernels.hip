@@ -69,45 +69,56 @@ __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ imgs
 // Level l >= 1: resize(level l-1 ROI -> level l ROI, INTER_LINEAR) then copyMakeBorder
 // REFLECT_101 (src/ORBextractor.cc:800-807), fused: every padded pixel is computed from the
 // interior pixel it reflects to.  Coefficient tables hold OpenCV's 11-bit fixed-point weights.
-// One workgroup produces a 256 x 32 pixel tile of the padded destination plane: it finds the
-// source rectangle its pixels read (column and row maps are monotone up to the border
-// reflection, so min/max of the per-thread entries bound it), stages that rectangle into LDS with
-// aligned 16-byte loads, and interpolates out of LDS.  One thread owns an aligned dword column
-// (4 pixels) of RZ_ROWS rows and keeps the horizontal interpolation of the lower source row for
-// the next output row, which usually needs it as its upper row.
-#define RZ_ROWS 8
+// One workgroup produces a 256 x 64 pixel tile of the padded destination plane.  The column and
+// row maps are monotone up to the border reflection, so the source rectangle of the tile follows
+// from the map values at the tile's ends and at the fold points inside it (four wave-uniform
+// table reads); that rectangle is staged into LDS with aligned 16-byte loads and the tile is
+// interpolated out of LDS.  One thread owns an aligned dword column (4 pixels) of RZ_ROWS rows
+// and keeps the horizontal interpolation of the lower source row for the next output row, which
+// usually needs it as its upper row.  A wave's rows are the same for all its lanes, so the row
+// tables are read through scalar loads.
+#define RZ_ROWS 16
 #define RZ_TILE_H (4 * RZ_ROWS)
+
+// extremes of reflect101(t, n) over t in [a, b] (a <= b): (min, max)
+__device__ __forceinline__ void reflect_range(int a, int b, int n, int& lo, int& hi) {
+    const int ra = reflect101(a, n), rb = reflect101(b, n);
+    lo = (a <= 0 && b >= 0) ? 0 : min(ra, rb);
+    hi = (a <= n - 1 && b >= n - 1) ? n - 1 : max(ra, rb);
+}
 
 // Rows [ybase, yend) of one dword column: vertical pass of cv::resize over horizontally
 // interpolated source rows read from `rows` (row r at rows + (r - row0) * rpitch).
+// "((b0 * (T0 >> 4)) >> 16) + ((b1 * (T1 >> 4)) >> 16) + 2) >> 2": the two products are taken as
+// the high halves of (b << 16) * (T >> 4).
 __device__ __forceinline__ void resize_rows(const uint8_t* __restrict__ rows, int rpitch, int row0, const int sx[4],
                                             const int sx1[4], const int a0[4], const int a1[4],
                                             const uint32_t* __restrict__ ytab_s, const uint32_t* __restrict__ ytab_b,
                                             int ybase, int yend, int h, uint8_t* __restrict__ dst, int dstride,
                                             uint32_t keep) {
     int cached_row = -1;
-    int ct[4] = {0, 0, 0, 0};
+    uint32_t ct[4] = {0, 0, 0, 0};
     for (int y = ybase; y < yend; y++) {
         const int dy = reflect101(y - ORB_EDGE, h);
         const uint32_t ys = ytab_s[dy], yb = ytab_b[dy];
         const int sy0 = ys & 0xffff, sy1 = ys >> 16;
-        const int b0 = yb & 0xffff, b1 = yb >> 16;
+        const uint32_t b0s = yb << 16, b1s = yb & 0xffff0000u;
         const int o1 = (sy1 - row0) * rpitch;
-        int t0[4], t1[4];
+        uint32_t t0[4], t1[4];
         if (sy0 == cached_row) {
 #pragma unroll
             for (int b = 0; b < 4; b++) t0[b] = ct[b];
         } else {
             const int o0 = (sy0 - row0) * rpitch;
 #pragma unroll
-            for (int b = 0; b < 4; b++) t0[b] = rows[o0 + sx[b]] * a0[b] + rows[o0 + sx1[b]] * a1[b];
+            for (int b = 0; b < 4; b++) t0[b] = (uint32_t)(rows[o0 + sx[b]] * a0[b] + rows[o0 + sx1[b]] * a1[b]) >> 4;
         }
 #pragma unroll
-        for (int b = 0; b < 4; b++) t1[b] = rows[o1 + sx[b]] * a0[b] + rows[o1 + sx1[b]] * a1[b];
+        for (int b = 0; b < 4; b++) t1[b] = (uint32_t)(rows[o1 + sx[b]] * a0[b] + rows[o1 + sx1[b]] * a1[b]) >> 4;
         uint32_t out = 0;
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            const uint32_t v = (uint32_t)((((b0 * (t0[b] >> 4)) >> 16) + ((b1 * (t1[b] >> 4)) >> 16) + 2) >> 2) & 0xff;
+            const uint32_t v = (__umulhi(b0s, t0[b]) + __umulhi(b1s, t1[b]) + 2u) >> 2;
             out |= v << (8 * b);
             ct[b] = t1[b];
         }
@@ -116,33 +127,55 @@ __device__ __forceinline__ void resize_rows(const uint8_t* __restrict__ rows, in
     }
 }
 
-
 __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, const GeomDev* __restrict__ g, int level,
                                                 const int* __restrict__ xofs, const uint32_t* __restrict__ xab,
                                                 const uint32_t* __restrict__ ysrc, const uint32_t* __restrict__ yab,
                                                 int lds_pitch, int lds_rows) {
     extern __shared__ uint4 rz_lds[];
-    __shared__ int bounds[4];  // min sx, max sx1, min sy0, max sy1
     const LevelGeom& L = g->lv[level];
     const LevelGeom& P = g->lv[level - 1];
     const int tid = threadIdx.y * 64 + threadIdx.x;
     int bx, by, f;
     xcd_frame_swizzle3(bx, by, f);
     const int dwx = bx * 64 + threadIdx.x;
-    const int ybase = (by * 4 + threadIdx.y) * RZ_ROWS;
+    const int wy = __builtin_amdgcn_readfirstlane((int)threadIdx.y);  // one wave per threadIdx.y: wave-uniform rows
+    const int ybase = (by * 4 + wy) * RZ_ROWS;
     uint8_t* frame = pyr + (long long)f * g->frame_bytes;
     const uint8_t* src = frame + P.plane_off + (long long)ORB_EDGE * P.stride + ORB_EDGE;
     const bool col_ok = dwx * 4 < L.stride;
     const int pw = L.w + 2 * ORB_EDGE;
-    if (tid == 0) {
-        bounds[0] = 0x7fffffff;
-        bounds[1] = 0;
-        bounds[2] = 0x7fffffff;
-        bounds[3] = 0;
+    // source rectangle of the whole tile (workgroup-uniform)
+    int dlo, dhi;
+    reflect_range(bx * 256 - ORB_EDGE, min(bx * 256 + 255, pw - 1) - ORB_EDGE, L.w, dlo, dhi);
+    const int X0 = xofs[L.rz_x_off + dlo] & ~15;
+    const int Xmax = min(xofs[L.rz_x_off + dhi] + 1, P.w - 1);
+    reflect_range(by * RZ_TILE_H - ORB_EDGE, min(by * RZ_TILE_H + RZ_TILE_H, L.ph) - 1 - ORB_EDGE, L.h, dlo, dhi);
+    const int sy_min = ysrc[L.rz_y_off + dlo] & 0xffff;
+    const int nrows = (int)(ysrc[L.rz_y_off + dhi] >> 16) - sy_min + 1;
+    const int pc = (Xmax - X0 + 16) >> 4;  // 16-byte chunks per staged row
+    // host sized the LDS for the level's scale; a tile that would not fit reads global memory
+    const bool staged = pc * 16 <= lds_pitch && nrows <= lds_rows && pc <= 32;
+    if (staged) {
+        // 32 lanes per source row, 8 rows per sweep of the workgroup, four rows in flight per lane
+        const int cj = tid & 31, r0 = tid >> 5;
+        if (cj < pc) {
+            const int lp4 = lds_pitch >> 4;
+            const uint8_t* s0 = src + (long long)sy_min * P.stride + X0 + 16 * cj;
+            for (int r = r0; r < nrows; r += 32) {
+                uint4 v[4];
+                int rr[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    rr[k] = min(r + 8 * k, nrows - 1);  // clamped rows store the same bytes again
+                    v[k] = *(const uint4*)(s0 + (long long)rr[k] * P.stride);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) rz_lds[rr[k] * lp4 + cj] = v[k];
+            }
+        }
     }
     int sx[4], sx1[4], a0[4], a1[4];
     uint32_t keep = 0;  // bytes of the dword that are inside the padded plane
-    int mn = 0x7fffffff, mx = 0;
 #pragma unroll
     for (int b = 0; b < 4; b++) {
         const int x = min(dwx * 4 + b, pw - 1);
@@ -153,45 +186,8 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, const
         const uint32_t xa = xab[L.rz_x_off + dx];
         a0[b] = xa & 0xffff;
         a1[b] = xa >> 16;
-        mn = min(mn, sx[b]);
-        mx = max(mx, sx1[b]);
     }
     const int yend = min(ybase + RZ_ROWS, L.ph);
-    int ymn = 0x7fffffff, ymx = 0;
-    for (int y = ybase; y < yend; y++) {
-        const uint32_t ys = ysrc[L.rz_y_off + reflect101(y - ORB_EDGE, L.h)];
-        ymn = min(ymn, (int)(ys & 0xffff));
-        ymx = max(ymx, (int)(ys >> 16));
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        mn = min(mn, __shfl_xor(mn, o));
-        mx = max(mx, __shfl_xor(mx, o));
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicMin(&bounds[0], mn);
-        atomicMax(&bounds[1], mx);
-        if (ybase < yend) {
-            atomicMin(&bounds[2], ymn);
-            atomicMax(&bounds[3], ymx);
-        }
-    }
-    __syncthreads();
-    const int X0 = bounds[0] & ~15;
-    const int nrows = bounds[3] - bounds[2] + 1;
-    const int pc = (bounds[1] - X0 + 16) >> 4;  // 16-byte chunks per staged row
-    const int sy_min = bounds[2];
-    // host sized the LDS for the level's scale; a tile that would not fit reads global memory
-    const bool staged = pc * 16 <= lds_pitch && nrows <= lds_rows;
-    if (staged) {
-        const int nchunk = pc * nrows;
-        const int lp4 = lds_pitch >> 4;
-        for (int i = tid; i < nchunk; i += 256) {
-            const int r = i / pc, k = i - r * pc;
-            rz_lds[r * lp4 + k] = *(const uint4*)(src + (long long)(sy_min + r) * P.stride + X0 + 16 * k);
-        }
-    }
     __syncthreads();
     if (!col_ok || ybase >= yend) return;
     uint8_t* dst = frame + L.plane_off + dwx * 4;
@@ -1001,7 +997,7 @@ void launch_resize(hipStream_t st, const GeomDev& hg, int batch, int level, uint
                    const int* xofs, const uint32_t* xab, const uint32_t* ysrc, const uint32_t* yab) {
     const LevelGeom& L = hg.lv[level];
     const LevelGeom& P = hg.lv[level - 1];
-    // source rectangle of a 256 x 32 destination tile at this level's scale, plus alignment slack
+    // source rectangle of a 256 x RZ_TILE_H destination tile at this level's scale, plus alignment slack
     const double sx = (double)P.w / L.w, sy = (double)P.h / L.h;
     int lds_pitch = ((int)(256 * sx) + 3 + 15 + 15) & ~15;
     int lds_rows = (int)(RZ_TILE_H * sy) + 4;

@@ -80,6 +80,22 @@
         if (s == 0x12345678u) out[0] = s;                                                           \
     }
 
+#define PROBESDWA(name, TEXT)                                                                       \
+    __global__ __launch_bounds__(256) void k_##name(uint32_t* out, uint32_t seed) {                 \
+        uint32_t r[CHAINS];                                                                         \
+        const uint32_t b = seed ^ threadIdx.x;                                                      \
+        for (int c = 0; c < CHAINS; c++) r[c] = seed * (c + 1) + threadIdx.x;                       \
+        for (int i = 0; i < ITERS; i++) {                                                           \
+            _Pragma("unroll") for (int c = 0; c < CHAINS; c++)                                      \
+                asm volatile(TEXT : "+v"(r[c]) : "v"(b));                                           \
+        }                                                                                           \
+        uint32_t s = 0;                                                                             \
+        for (int c = 0; c < CHAINS; c++) s ^= r[c];                                                 \
+        if (s == 0x12345678u) out[0] = s;                                                           \
+    }
+PROBESDWA(add_sdwa_w1, "v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1")
+PROBESDWA(lshr_sdwa_b1, "v_lshrrev_b32_sdwa %0, %1, %0 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD")
+PROBESDWA(add_dpp, "v_add_u32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf")
 PROBE2(add_u32, "v_add_u32")
 PROBE2(sub_u32, "v_sub_u32")
 PROBE2(xor_b32, "v_xor_b32")
@@ -95,6 +111,14 @@ PROBE2(pk_max_i16, "v_pk_max_i16")
 PROBE2(pk_add_u16, "v_pk_add_u16")
 PROBE2(pk_mul_lo_u16, "v_pk_mul_lo_u16")
 PROBE2(bcnt, "v_bcnt_u32_b32")
+PROBE2(mul_hi_u32, "v_mul_hi_u32")
+PROBE2(mul_hi_u32_u24, "v_mul_hi_u32_u24")
+PROBE2(lshlrev, "v_lshlrev_b32")
+PROBE2(or_b32, "v_or_b32")
+PROBE2(ashrrev, "v_ashrrev_i32")
+PROBE2(cndmask, "v_cndmask_b32")
+PROBE2(add_f16, "v_add_f16")
+PROBE2(pk_fma_dummy, "v_pk_lshrrev_b16")
 PROBE2(mul_f32, "v_mul_f32")
 PROBE2(add_f32, "v_add_f32")
 PROBE2(max_f32, "v_max_f32")
@@ -117,6 +141,12 @@ PROBE3(sad_u8, "v_sad_u8")
 PROBE3(sad_u32, "v_sad_u32")
 PROBE3(fma_f32, "v_fma_f32")
 PROBE3(xad_u32, "v_xad_u32")
+PROBE3(mad_u32_u16, "v_mad_u32_u16")
+PROBE3(add_lshl, "v_add_lshl_u32")
+PROBE3(or3, "v_or3_b32")
+PROBE3(min3_f32, "v_min3_f32")
+PROBE3(pk_mad_u16, "v_pk_mad_u16")
+PROBE3(cvt_pk_u8_f32, "v_cvt_pk_u8_f32")
 PROBE1(mov_b32, "v_mov_b32")
 PROBE1(cvt_f32_i32, "v_cvt_f32_i32")
 PROBE1(cvt_f32_ubyte0, "v_cvt_f32_ubyte0")
@@ -160,12 +190,12 @@ int main() {
         printf("%-22s %8.3f ms  %.3e wave-instr/s  %.2f SIMD-cycles/instr\n", name, best, rate, cus * 4.0 * clk / rate);
     };
 #define RUN(name) run(#name, k_##name)
-    RUN(add_u32); RUN(sub_u32); RUN(xor_b32); RUN(and_b32); RUN(min_i32); RUN(max_u32); RUN(lshrrev);
+    RUN(add_sdwa_w1); RUN(lshr_sdwa_b1); RUN(add_dpp); RUN(add_u32); RUN(sub_u32); RUN(xor_b32); RUN(and_b32); RUN(min_i32); RUN(max_u32); RUN(lshrrev);
     RUN(mul_lo_u32); RUN(mul_u32_u24); RUN(pk_sub_i16); RUN(pk_min_i16); RUN(pk_max_i16); RUN(pk_add_u16);
     RUN(pk_mul_lo_u16); RUN(bcnt); RUN(mul_f32); RUN(add_f32); RUN(mbcnt_lo);
     RUN(min3_i32); RUN(max3_i32); RUN(med3_i32); RUN(perm_b32); RUN(mad_i32_i24); RUN(mad_u32_u24);
     RUN(lshl_add_u32); RUN(add3_u32); RUN(and_or_b32); RUN(lshl_or_b32); RUN(bfe_u32); RUN(alignbyte);
-    RUN(dot4_u32_u8); RUN(dot2_u32_u16); RUN(sad_u8); RUN(sad_u32); RUN(fma_f32); RUN(xad_u32); RUN(max_f32);
+    RUN(dot4_u32_u8); RUN(dot2_u32_u16); RUN(sad_u8); RUN(sad_u32); RUN(fma_f32); RUN(xad_u32); RUN(max_f32); RUN(mul_hi_u32); RUN(mul_hi_u32_u24); RUN(lshlrev); RUN(or_b32); RUN(ashrrev); RUN(cndmask); RUN(add_f16); RUN(pk_fma_dummy); RUN(mad_u32_u16); RUN(add_lshl); RUN(or3); RUN(min3_f32); RUN(pk_mad_u16); RUN(cvt_pk_u8_f32);
     RUN(mov_b32); RUN(cvt_f32_i32); RUN(cvt_f32_ubyte0); RUN(rndne_f32); RUN(rcp_f32); RUN(ffbl);
     RUN(mul_f64); RUN(add_f64); RUN(pk_mul_f32); RUN(pk_add_f32);
     RUN(ds_read_b32); RUN(ds_read_u8); RUN(ds_read_u8_spread); RUN(ds_read_u16);
