@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void k_nms(const uint8_t* __restrict__ score, 
     extern __shared__ int sh[];  // [0,ch): counts/offsets at fastTh, [ch,2ch): at 7, then 2*256 partials + 2
     const int c = blockIdx.x, f = blockIdx.y;
     const CellDesc cd = cells[c];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     int* out_total = n_total + (long long)f * g->cells_per_frame + c;
     if (cd.cw <= 0 || cd.ch <= 0) {
         if (tid == 0) *out_total = 0;
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256) void k_cell_select(const GeomDev* __restrict__
     __shared__ uint16_t lists[4 * 2 * SEL_WCAP];
     int bx = blockIdx.x, f = blockIdx.y;
     xcd_frame_swizzle(bx, f, (int)gridDim.x, (int)gridDim.y);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int c = bx * 4 + wave;
     if (c >= g->cells_per_frame) return;
     const long long fc = (long long)f * g->cells_per_frame + c;
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(256) void k_level_select(const GeomDev* __restrict_
     __shared__ int red[4];
     const int level = blockIdx.x, f = blockIdx.y;
     const LevelGeom& L = g->lv[level];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int nCells = L.nCells;
     const CellDesc* lc = cells + L.cell_base;
     const int* ret = n_retain + (long long)f * g->cells_per_frame + L.cell_base;
@@ -684,7 +684,8 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
     xcd_frame_swizzle3(bx, by, f);
     const int ndw = L.stride >> 2;
     const int dwx = bx * 64 + threadIdx.x;
-    const int y0 = (by * 4 + threadIdx.y) * BL_ROWS;
+    // one wave per threadIdx.y: the rows a wave walks are the same for all its lanes (scalar row arithmetic)
+    const int y0 = (by * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.y)) * BL_ROWS;
     const int ph = L.ph;
     if (dwx >= ndw || y0 >= ph) return;
     const long long base = (long long)f * g->frame_bytes + L.plane_off;

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(FC_THREADS) void k_fast_cell(const uint8_t* __restr
     int c = blockIdx.x, f = blockIdx.y;
     xcd_frame_swizzle(c, f, (int)gridDim.x, (int)gridDim.y);
     const CellDesc cd = cells[c];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     int* out_total = n_total + (long long)f * g->cells_per_frame + c;
     if (cd.cw <= 0 || cd.ch <= 0) {
         if (tid == 0) *out_total = 0;
