@@ -374,7 +374,43 @@ def bow_leg(orb, torch, dev, orbref, m):
     rword, rnode, _ = ref.transform_features(f[:2000], 4)
     cdt = time.perf_counter() - t0
     ok = np.array_equal(word[:2000].cpu().numpy(), rword) and np.array_equal(node[:2000].cpu().numpy(), rnode)
-    return {"descriptors": n, "tree": "k=%d L=%d (%d nodes, synthetic)" % (k, L, len(parent)), "ms": round(best * 1e3, 3),
+    # SearchByBoW (KeyFrame/KeyFrame form) over 256 pairs of 2000 features: ComputeBoW of both batches, then the match
+    b, nf = 256, 2000
+    kp = np.zeros((b, nf, 7), np.float32)
+    kp[:, :, 3] = rng.uniform(0, 360, (b, nf))
+    d1 = f.reshape(b, nf, 32)
+    flips = rng.integers(0, 256, (b, nf, 32), dtype=np.uint8)
+    for _ in range(4):
+        flips &= rng.integers(0, 256, (b, nf, 32), dtype=np.uint8)
+    d2 = d1 ^ flips
+    cnt = torch.full((b,), nf, dtype=torch.int32, device=cuda)
+    mm = orb.ORBmatcher(0.8, True, device=dev)
+    F1 = orb.FrameBatch(mm, torch.from_numpy(kp).to(cuda), torch.from_numpy(d1).to(cuda), cnt, [0, 0, 1280, 720])
+    F2 = orb.FrameBatch(mm, torch.from_numpy(kp).to(cuda), torch.from_numpy(d2).to(cuda), cnt, [0, 0, 1280, 720])
+    t0 = time.perf_counter()
+    F1.ComputeBoW(voc, 3, node_cap=1024)
+    F2.ComputeBoW(voc, 3, node_cap=1024)
+    t_bow = (time.perf_counter() - t0) / 2
+    ones = torch.ones((b, nf), dtype=torch.uint8, device=cuda)
+    tsb = []
+    for _ in range(4):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        nm, m12, _ = mm.SearchByBoW(F1, F2, ones, ones)
+        tsb.append(time.perf_counter() - t0)
+    tb = float(np.median(tsb[1:]))
+    fv1, fv2 = F1.feature_vector(0), F2.feature_vector(0)
+    hk = kp[0].view(orbref.KP_DTYPE).reshape(nf)
+    t0 = time.perf_counter()
+    rn, r12 = orbref.search_by_bow_kf_kf(hk, d1[0], np.ones(nf, np.uint8), fv1, hk, d2[0], np.ones(nf, np.uint8), fv2,
+                                         mm.mfNNratio, True)
+    ct = time.perf_counter() - t0
+    sbow = {"pairs": b, "features": nf, "ms": round(tb * 1e3, 3), "pairs_per_sec": round(b / tb, 1),
+            "compute_bow_ms_per_%d_frames" % b: round(t_bow * 1e3, 3), "mean_matches_per_pair": round(float(nm.float().mean().item()), 1),
+            "cpu_oracle_1_thread_pairs_per_sec": round(1 / ct, 1),
+            "parity_pair0": bool(rn == int(nm[0].item()) and np.array_equal(r12, m12[0].cpu().numpy()))}
+    return {"search_by_bow": sbow,
+            "descriptors": n, "tree": "k=%d L=%d (%d nodes, synthetic)" % (k, L, len(parent)), "ms": round(best * 1e3, 3),
             "descriptors_per_sec": float("%.4g" % (n / best)),
             "cpu_oracle_1_thread_descriptors_per_sec": float("%.4g" % (2000 / cdt)), "parity_first_2000": bool(ok)}
 

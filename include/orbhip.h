@@ -264,6 +264,35 @@ int orbhip_vocabulary_words(const orbhip_vocabulary* v);
 int orbhip_bow_transform_device(orbhip_matcher* m, const orbhip_vocabulary* v, const uint8_t* d_desc, int n, int levelsup,
                                 int32_t* d_word, int32_t* d_node, double* d_weight);
 
+/* FeatureVector of each of `batch` frames from the per-descriptor outputs of
+ * orbhip_bow_transform_device (frame f: d_n[f] descriptors at d_node + f*cap, d_weight + f*cap), as
+ * transform(features, v, fv, levelsup) fills it (TemplatedVocabulary.h:1150-1163, FeatureVector.cpp:
+ * 31-45): descriptors with weight > 0 grouped by node, nodes ascending, feature indices ascending.
+ * Frame f: d_fv_count[f] nodes d_fv_nodes[f*node_cap ...], features of node j at
+ * d_fv_feat[f*cap + d_fv_start[f*(node_cap+1) + j] ... d_fv_start[f*(node_cap+1) + j + 1]).  More than
+ * node_cap distinct nodes make the next orbhip_matcher_synchronize fail with ORBHIP_ECAP.
+ * Device pointers; asynchronous. */
+int orbhip_feature_vector_device(orbhip_matcher* m, const int32_t* d_node, const double* d_weight, const int32_t* d_n,
+                                 int batch, int cap, int node_cap, int32_t* d_fv_nodes, int32_t* d_fv_start,
+                                 int32_t* d_fv_feat, int32_t* d_fv_count);
+/* Replaces ORBmatcher::SearchByBoW for `batch` independent pairs, in both of its forms:
+ *   th_low_inclusive = 1, d_valid2 = NULL: SearchByBoW(KeyFrame* pKF, Frame &F, ...) (src/ORBmatcher.cc:
+ *     158-295) with 1 = the keyframe, 2 = the frame; vpMapPointMatches[iF] = the keyframe's map point
+ *     d_matches21[iF] (or NULL where that is -1);
+ *   th_low_inclusive = 0: SearchByBoW(KeyFrame*, KeyFrame*, ...) (:726-861); vpMatches12[i1] = map point
+ *     d_matches12[i1] of keyframe 2.
+ * d_valid1 / d_valid2 (cap bytes per frame): the keyframe's map point exists and is not bad.
+ * FeatureVectors in the layout of orbhip_feature_vector_device.  d_nmatches (batch): the return value.
+ * Device pointers; asynchronous. */
+int orbhip_search_by_bow_device(orbhip_matcher* m, const OrbKeypoint* d_kp1, const uint8_t* d_desc1, const int32_t* d_n1,
+                                const uint8_t* d_valid1, const int32_t* d_fv1_nodes, const int32_t* d_fv1_start,
+                                const int32_t* d_fv1_feat, const int32_t* d_fv1_count, const OrbKeypoint* d_kp2,
+                                const uint8_t* d_desc2, const int32_t* d_n2, const uint8_t* d_valid2,
+                                const int32_t* d_fv2_nodes, const int32_t* d_fv2_start, const int32_t* d_fv2_feat,
+                                const int32_t* d_fv2_count, int batch, int cap, int node_cap, float nnratio,
+                                int check_orientation, int th_low_inclusive, int32_t* d_matches12, int32_t* d_matches21,
+                                int32_t* d_nmatches);
+
 /* Device self-tests of the arithmetic helpers (test instrumentation, host pointers, blocking):
  * which 0: n (y, x) float pairs -> n floats, the device's fastAtan2 in degrees
  *       1: n float angles (radians) -> n (cos, sin) float pairs as the descriptor kernel computes them

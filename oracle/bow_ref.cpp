@@ -13,8 +13,12 @@
 //   BowVector::addWeight/addIfNotExist/normalize   BowVector.cpp:34-84
 //   FeatureVector::addFeature          FeatureVector.cpp:31-45
 //   L1Scoring::score                   ScoringObject.cpp:23-68
+// and of the two matchers restricted to features under the same vocabulary node:
+//   ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...)      src/ORBmatcher.cc:158-295
+//   ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, ...)   src/ORBmatcher.cc:726-861
 #include "orb_ref.h"
 
+#include <climits>
 #include <cmath>
 #include <map>
 #include <vector>
@@ -226,6 +230,179 @@ double orbref_bow_score_l1(const int32_t* w1, const double* v1, int n1, const in
     }
     score = -score / 2.0;
     return score;
+}
+
+namespace {
+
+struct KpB {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+};
+
+FeatureVector fv_from_csr(const int32_t* nodes, const int32_t* start, const int32_t* feat, int nnodes) {
+    FeatureVector fv;
+    for (int j = 0; j < nnodes; j++)
+        for (int i = start[j]; i < start[j + 1]; i++) fv.addFeature((NodeId)nodes[j], (unsigned)feat[i]);
+    return fv;
+}
+
+const int BOW_HISTO_LENGTH = 30, BOW_TH_LOW = 20;
+
+}  // namespace
+
+// src/ORBmatcher.cc:158-295.  validKF[i] != 0 <=> vpMapPointsKF[i] exists and is not bad.
+// matchesF[iF] = index in the keyframe whose map point goes to feature iF of the frame, or -1.
+int orbref_search_by_bow_kf_frame(const void* kpKF_, const uint8_t* descKF, int nKF, const uint8_t* validKF,
+                                  const int32_t* fvKF_nodes, const int32_t* fvKF_start, const int32_t* fvKF_feat,
+                                  int fvKF_n, const void* kpF_, const uint8_t* descF, int nF, const int32_t* fvF_nodes,
+                                  const int32_t* fvF_start, const int32_t* fvF_feat, int fvF_n, float mfNNratio,
+                                  int mbCheckOrientation, int32_t* matchesF) {
+    const KpB* kpKF = (const KpB*)kpKF_;
+    const KpB* kpF = (const KpB*)kpF_;
+    for (int i = 0; i < nF; i++) matchesF[i] = -1;
+    FeatureVector vFeatVecKF = fv_from_csr(fvKF_nodes, fvKF_start, fvKF_feat, fvKF_n);
+    FeatureVector FmFeatVec = fv_from_csr(fvF_nodes, fvF_start, fvF_feat, fvF_n);
+    int nmatches = 0;
+    std::vector<int> rotHist[BOW_HISTO_LENGTH];
+    const float factor = 1.0f / BOW_HISTO_LENGTH;
+    FeatureVector::iterator KFit = vFeatVecKF.begin(), Fit = FmFeatVec.begin();
+    FeatureVector::iterator KFend = vFeatVecKF.end(), Fend = FmFeatVec.end();
+    while (KFit != KFend && Fit != Fend) {
+        if (KFit->first == Fit->first) {
+            std::vector<unsigned int> vIndicesKF = KFit->second;
+            std::vector<unsigned int> vIndicesF = Fit->second;
+            for (size_t iKF = 0, iendKF = vIndicesKF.size(); iKF < iendKF; iKF++) {
+                const unsigned int realIdxKF = vIndicesKF[iKF];
+                if ((int)realIdxKF >= nKF) continue;  // vpMapPointsKF.at() throws -> continue
+                if (!validKF[realIdxKF]) continue;
+                const uint8_t* dKF = descKF + (size_t)realIdxKF * 32;
+                int bestDist1 = INT_MAX;
+                int bestIdxF = -1;
+                int bestDist2 = INT_MAX;
+                for (size_t iF = 0, iendF = vIndicesF.size(); iF < iendF; iF++) {
+                    const unsigned int realIdxF = vIndicesF[iF];
+                    if (matchesF[realIdxF] >= 0) continue;  // "if(vpMapPointMatches[realIdxF]) continue;"
+                    const int dist = orbref_hamming(dKF, descF + (size_t)realIdxF * 32);
+                    if (dist < bestDist1) {
+                        bestDist2 = bestDist1;
+                        bestDist1 = dist;
+                        bestIdxF = realIdxF;
+                    } else if (dist < bestDist2) {
+                        bestDist2 = dist;
+                    }
+                }
+                if (bestDist1 <= BOW_TH_LOW) {
+                    if (static_cast<float>(bestDist1) < mfNNratio * static_cast<float>(bestDist2)) {
+                        matchesF[bestIdxF] = (int32_t)realIdxKF;
+                        if (mbCheckOrientation) {
+                            float rot = kpKF[realIdxKF].angle - kpF[bestIdxF].angle;
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = std::round(rot * factor);
+                            if (bin == BOW_HISTO_LENGTH) bin = 0;
+                            rotHist[bin].push_back(bestIdxF);
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            KFit++;
+            Fit++;
+        } else if (KFit->first < Fit->first) {
+            KFit = vFeatVecKF.lower_bound(Fit->first);
+        } else {
+            Fit = FmFeatVec.lower_bound(KFit->first);
+        }
+    }
+    if (mbCheckOrientation) {
+        int32_t sizes[BOW_HISTO_LENGTH], ind[3];
+        for (int i = 0; i < BOW_HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        orbref_three_maxima(sizes, BOW_HISTO_LENGTH, ind);
+        for (int i = 0; i < BOW_HISTO_LENGTH; i++) {
+            if (i == ind[0] || i == ind[1] || i == ind[2]) continue;
+            for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+                matchesF[rotHist[i][j]] = -1;
+                nmatches--;
+            }
+        }
+    }
+    return nmatches;
+}
+
+// src/ORBmatcher.cc:726-861.  valid1 / valid2: the keyframes' map points exist and are not bad.
+// matches12[idx1] = index in keyframe 2 whose map point goes to vpMatches12[idx1], or -1.
+int orbref_search_by_bow_kf_kf(const void* kp1_, const uint8_t* desc1, int n1, const uint8_t* valid1,
+                               const int32_t* fv1_nodes, const int32_t* fv1_start, const int32_t* fv1_feat, int fv1_n,
+                               const void* kp2_, const uint8_t* desc2, int n2, const uint8_t* valid2,
+                               const int32_t* fv2_nodes, const int32_t* fv2_start, const int32_t* fv2_feat, int fv2_n,
+                               float mfNNratio, int mbCheckOrientation, int32_t* matches12) {
+    const KpB* vKeysUn1 = (const KpB*)kp1_;
+    const KpB* vKeysUn2 = (const KpB*)kp2_;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    std::vector<bool> vbMatched2(n2, false);
+    FeatureVector vFeatVec1 = fv_from_csr(fv1_nodes, fv1_start, fv1_feat, fv1_n);
+    FeatureVector vFeatVec2 = fv_from_csr(fv2_nodes, fv2_start, fv2_feat, fv2_n);
+    std::vector<int> rotHist[BOW_HISTO_LENGTH];
+    const float factor = 1.0f / BOW_HISTO_LENGTH;
+    int nmatches = 0;
+    FeatureVector::iterator f1it = vFeatVec1.begin(), f2it = vFeatVec2.begin();
+    FeatureVector::iterator f1end = vFeatVec1.end(), f2end = vFeatVec2.end();
+    while (f1it != f1end && f2it != f2end) {
+        if (f1it->first == f2it->first) {
+            for (size_t i1 = 0, iend1 = f1it->second.size(); i1 < iend1; i1++) {
+                size_t idx1 = f1it->second[i1];
+                if (!valid1[idx1]) continue;
+                const uint8_t* d1 = desc1 + idx1 * 32;
+                int bestDist1 = INT_MAX;
+                int bestIdx2 = -1;
+                int bestDist2 = INT_MAX;
+                for (size_t i2 = 0, iend2 = f2it->second.size(); i2 < iend2; i2++) {
+                    size_t idx2 = f2it->second[i2];
+                    if (vbMatched2[idx2] || !valid2[idx2]) continue;
+                    int dist = orbref_hamming(d1, desc2 + idx2 * 32);
+                    if (dist < bestDist1) {
+                        bestDist2 = bestDist1;
+                        bestDist1 = dist;
+                        bestIdx2 = (int)idx2;
+                    } else if (dist < bestDist2) {
+                        bestDist2 = dist;
+                    }
+                }
+                if (bestDist1 < BOW_TH_LOW) {
+                    if (static_cast<float>(bestDist1) < mfNNratio * static_cast<float>(bestDist2)) {
+                        matches12[idx1] = bestIdx2;
+                        vbMatched2[bestIdx2] = true;
+                        if (mbCheckOrientation) {
+                            float rot = vKeysUn1[idx1].angle - vKeysUn2[bestIdx2].angle;
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = std::round(rot * factor);
+                            if (bin == BOW_HISTO_LENGTH) bin = 0;
+                            rotHist[bin].push_back((int)idx1);
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            f1it++;
+            f2it++;
+        } else if (f1it->first < f2it->first) {
+            f1it = vFeatVec1.lower_bound(f2it->first);
+        } else {
+            f2it = vFeatVec2.lower_bound(f1it->first);
+        }
+    }
+    if (mbCheckOrientation) {
+        int32_t sizes[BOW_HISTO_LENGTH], ind[3];
+        for (int i = 0; i < BOW_HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        orbref_three_maxima(sizes, BOW_HISTO_LENGTH, ind);
+        for (int i = 0; i < BOW_HISTO_LENGTH; i++) {
+            if (i == ind[0] || i == ind[1] || i == ind[2]) continue;
+            for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+                matches12[rotHist[i][j]] = -1;
+                nmatches--;
+            }
+        }
+    }
+    return nmatches;
 }
 
 }  // extern "C"

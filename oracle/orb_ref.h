@@ -139,6 +139,19 @@ void orbref_bow_transform_feature(const orbref_vocabulary* v, const uint8_t* fea
 int orbref_bow_transform(const orbref_vocabulary* v, const uint8_t* features, int n, int levelsup, int32_t* bow_words,
                          double* bow_values, int32_t* n_words, int32_t* fv_nodes, int32_t* fv_start, int32_t* fv_features,
                          int32_t* n_nodes);
+/* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (src/ORBmatcher.cc:158-295) and
+ * SearchByBoW(KeyFrame*, KeyFrame*, ...) (:726-861).  FeatureVectors as sorted nodes with CSR lists of
+ * feature indices; valid*: the keyframe's map point exists and is not bad. */
+int orbref_search_by_bow_kf_frame(const void* kpKF, const uint8_t* descKF, int nKF, const uint8_t* validKF,
+                                  const int32_t* fvKF_nodes, const int32_t* fvKF_start, const int32_t* fvKF_feat,
+                                  int fvKF_n, const void* kpF, const uint8_t* descF, int nF, const int32_t* fvF_nodes,
+                                  const int32_t* fvF_start, const int32_t* fvF_feat, int fvF_n, float nnratio,
+                                  int check_orientation, int32_t* matchesF);
+int orbref_search_by_bow_kf_kf(const void* kp1, const uint8_t* desc1, int n1, const uint8_t* valid1,
+                               const int32_t* fv1_nodes, const int32_t* fv1_start, const int32_t* fv1_feat, int fv1_n,
+                               const void* kp2, const uint8_t* desc2, int n2, const uint8_t* valid2,
+                               const int32_t* fv2_nodes, const int32_t* fv2_start, const int32_t* fv2_feat, int fv2_n,
+                               float nnratio, int check_orientation, int32_t* matches12);
 /* L1Scoring::score (ScoringObject.cpp:23-68). */
 double orbref_bow_score_l1(const int32_t* w1, const double* v1, int n1, const int32_t* w2, const double* v2, int n2);
 

@@ -81,6 +81,8 @@ def lib():
         L.orbref_bow_transform_feature.argtypes = [vp, vp, i32, vp, vp, vp]
         L.orbref_bow_transform_feature.restype = None
         L.orbref_bow_transform.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+        L.orbref_search_by_bow_kf_frame.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, i32, f32, i32, vp]
+        L.orbref_search_by_bow_kf_kf.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, f32, i32, vp]
         L.orbref_bow_score_l1.restype = C.c_double
         L.orbref_bow_score_l1.argtypes = [vp, vp, i32, vp, vp, i32]
         L.orbref_distinctive_descriptor.argtypes = [vp, i32, vp]
@@ -303,3 +305,37 @@ def bow_score_l1(a, b):
     w1, v1 = np.ascontiguousarray(a[0], np.int32), np.ascontiguousarray(a[1], np.float64)
     w2, v2 = np.ascontiguousarray(b[0], np.int32), np.ascontiguousarray(b[1], np.float64)
     return lib().orbref_bow_score_l1(_p(w1), _p(v1), len(w1), _p(w2), _p(v2), len(w2))
+
+
+def _fv_arrays(fv):
+    nodes, start, feat = fv
+    return (np.ascontiguousarray(nodes, np.int32), np.ascontiguousarray(start, np.int32),
+            np.ascontiguousarray(feat if len(feat) else np.zeros(1), np.int32))
+
+
+def search_by_bow_kf_frame(kpKF, descKF, validKF, fvKF, kpF, descF, fvF, nnratio=0.7, check_orientation=True):
+    """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...): (nmatches, matchesF[nF] = keyframe index or -1)."""
+    kpKF, kpF = np.ascontiguousarray(kpKF, KP_DTYPE), np.ascontiguousarray(kpF, KP_DTYPE)
+    descKF = np.ascontiguousarray(descKF, np.uint8).reshape(-1, 32)
+    descF = np.ascontiguousarray(descF, np.uint8).reshape(-1, 32)
+    validKF = np.ascontiguousarray(validKF, np.uint8)
+    a, b = _fv_arrays(fvKF), _fv_arrays(fvF)
+    out = np.full(max(len(kpF), 1), -1, np.int32)
+    n = lib().orbref_search_by_bow_kf_frame(_p(kpKF), _p(descKF), len(kpKF), _p(validKF), _p(a[0]), _p(a[1]), _p(a[2]),
+                                            len(a[0]), _p(kpF), _p(descF), len(kpF), _p(b[0]), _p(b[1]), _p(b[2]), len(b[0]),
+                                            nnratio, int(check_orientation), _p(out))
+    return n, out[:len(kpF)].copy()
+
+
+def search_by_bow_kf_kf(kp1, desc1, valid1, fv1, kp2, desc2, valid2, fv2, nnratio=0.8, check_orientation=True):
+    """ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, ...): (nmatches, matches12[n1] = index in keyframe 2 or -1)."""
+    kp1, kp2 = np.ascontiguousarray(kp1, KP_DTYPE), np.ascontiguousarray(kp2, KP_DTYPE)
+    desc1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32)
+    desc2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+    valid1, valid2 = np.ascontiguousarray(valid1, np.uint8), np.ascontiguousarray(valid2, np.uint8)
+    a, b = _fv_arrays(fv1), _fv_arrays(fv2)
+    out = np.full(max(len(kp1), 1), -1, np.int32)
+    n = lib().orbref_search_by_bow_kf_kf(_p(kp1), _p(desc1), len(kp1), _p(valid1), _p(a[0]), _p(a[1]), _p(a[2]), len(a[0]),
+                                         _p(kp2), _p(desc2), len(kp2), _p(valid2), _p(b[0]), _p(b[1]), _p(b[2]), len(b[0]),
+                                         nnratio, int(check_orientation), _p(out))
+    return n, out[:len(kp1)].copy()

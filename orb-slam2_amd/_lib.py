@@ -99,6 +99,8 @@ def lib():
     L.orbhip_vocabulary_destroy.argtypes = [vp]
     L.orbhip_vocabulary_destroy.restype = None
     L.orbhip_vocabulary_words.argtypes = [vp]
+    L.orbhip_feature_vector_device.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
+    L.orbhip_search_by_bow_device.argtypes = [vp] + [vp] * 16 + [i32, i32, i32, f32, i32, i32, vp, vp, vp]
     L.orbhip_bow_transform_device.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
     L.orbhip_distinctive_descriptors_device.argtypes = [vp, vp, vp, i32, vp, vp]
     L.orbhip_window_search_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, OrbFrameBounds,

@@ -13,6 +13,7 @@
 // 512-byte run of node descriptors.
 #include <hip/hip_runtime.h>
 
+#include <climits>
 #include <vector>
 
 #include "matcher_internal.h"
@@ -163,6 +164,323 @@ int orbhip_bow_transform_device(orbhip_matcher* m, const orbhip_vocabulary* v, c
     hipLaunchKernelGGL(k_bow_transform, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, m->stream, v->d_child_start,
                        v->d_child_ids, v->d_desc, v->d_word, v->d_weight, v->L, levelsup, d_desc, n, d_word, d_node, d_weight);
     HIPCHK(hipGetLastError());
+    return ORBHIP_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// FeatureVector of a frame (Thirdparty/DBoW2/DBoW2/FeatureVector.cpp:31-45 driven by
+// TemplatedVocabulary.h:1150-1163): features with weight > 0 grouped by node id, nodes ascending,
+// feature indices ascending inside a node.  One workgroup per frame sorts 64-bit keys
+// (node << 32 | feature) in LDS and cuts the sorted run at node changes.
+namespace {
+
+#define FV_THREADS 256
+
+__global__ __launch_bounds__(FV_THREADS) void k_feature_vector(const int32_t* __restrict__ node, const double* __restrict__ weight,
+                                                               const int32_t* __restrict__ n_arr, int cap, int node_cap,
+                                                               int32_t* __restrict__ fv_nodes, int32_t* __restrict__ fv_start,
+                                                               int32_t* __restrict__ fv_feat, int32_t* __restrict__ fv_count,
+                                                               int* __restrict__ err) {
+    extern __shared__ unsigned long long fkeys[];
+    __shared__ int nvalid_sh, nnodes_sh;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int n = min(max(n_arr[f], 0), cap);
+    int np2 = 64;
+    while (np2 < n) np2 <<= 1;
+    if (tid == 0) {
+        nvalid_sh = 0;
+        nnodes_sh = 0;
+    }
+    for (int i = tid; i < np2; i += FV_THREADS) {
+        unsigned long long key = 0xffffffffffffffffull;
+        if (i < n && weight[(long long)f * cap + i] > 0) key = ((unsigned long long)(uint32_t)node[(long long)f * cap + i] << 32) | (uint32_t)i;
+        fkeys[i] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (np2 >> 1); t += FV_THREADS) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int hi = lo | j;
+                const unsigned long long a = fkeys[lo], b = fkeys[hi];
+                const bool up = (lo & k) == 0;
+                if ((a > b) == up) {
+                    fkeys[lo] = b;
+                    fkeys[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    // feature indices in sorted order; a node starts where the upper word changes.  Node slots are
+    // claimed in sorted order by counting the starts before each position (block-wide scan).
+    int32_t* feat = fv_feat + (long long)f * cap;
+    int32_t* nodes = fv_nodes + (long long)f * node_cap;
+    int32_t* start = fv_start + (long long)f * (node_cap + 1);
+    __shared__ int wsum[FV_THREADS / 64];
+    __shared__ int carry;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    int nvalid = 0;
+    for (int base = 0; base < np2; base += FV_THREADS) {
+        const int i = base + tid;
+        const unsigned long long key = i < np2 ? fkeys[i] : 0xffffffffffffffffull;
+        const bool valid = key != 0xffffffffffffffffull;
+        const bool head = valid && (i == 0 || (uint32_t)(fkeys[i - 1] >> 32) != (uint32_t)(key >> 32));
+        if (valid) feat[i] = (int32_t)(key & 0xffffffffu);
+        int incl = head ? 1 : 0;
+        const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int off = carry;
+        for (int w = 0; w < wave; w++) off += wsum[w];
+        if (head) {
+            const int slot = off + incl - 1;
+            if (slot < node_cap) {
+                nodes[slot] = (int32_t)(key >> 32);
+                start[slot] = i;
+            }
+        }
+        nvalid += valid ? 1 : 0;
+        __syncthreads();
+        if (tid == FV_THREADS - 1) carry = off + incl;
+        __syncthreads();
+    }
+    // total number of valid features = position of the first invalid key (keys are sorted)
+    atomicAdd(&nvalid_sh, nvalid);
+    __syncthreads();
+    if (tid == 0) {
+        const int nn = carry;
+        if (nn > node_cap) atomicOr(err, 16);
+        const int kept = min(nn, node_cap);
+        start[kept] = nvalid_sh;
+        fv_count[f] = kept;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SearchByBoW (src/ORBmatcher.cc:158-295 and :726-861): features under the same vocabulary node are
+// matched with the best / second-best scan; a feature of the second frame is taken at most once.
+// Nodes are independent (a feature lies under exactly one node), so one wave handles one node of
+// the first frame: it finds the node in the second frame's sorted node list, walks the first
+// frame's features of the node in order and lets its 64 lanes examine the second frame's list.
+#define BOW_HISTO_LENGTH 30
+#define BOW_TH_LOW 20
+
+struct KpDevB {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+};
+
+__global__ __launch_bounds__(64) void k_bow_match(const uint8_t* __restrict__ desc1, const uint8_t* __restrict__ valid1,
+                                                  const int32_t* __restrict__ fv1_nodes, const int32_t* __restrict__ fv1_start,
+                                                  const int32_t* __restrict__ fv1_feat, const int32_t* __restrict__ fv1_count,
+                                                  const uint8_t* __restrict__ desc2, const uint8_t* __restrict__ valid2,
+                                                  const int32_t* __restrict__ fv2_nodes, const int32_t* __restrict__ fv2_start,
+                                                  const int32_t* __restrict__ fv2_feat, const int32_t* __restrict__ fv2_count,
+                                                  int cap, int node_cap, float ratio, int th_inclusive,
+                                                  int32_t* __restrict__ matches12, int32_t* __restrict__ matches21,
+                                                  int32_t* __restrict__ nmatches) {
+    __shared__ uint8_t taken[ORBHIP_FRAME_MAX_KEYPOINTS];
+    const int j = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+    if (j >= fv1_count[f]) return;
+    const int node = fv1_nodes[(long long)f * node_cap + j];
+    // lower bound of `node` in the second frame's node list
+    const int32_t* n2 = fv2_nodes + (long long)f * node_cap;
+    int lo = 0, hi = fv2_count[f];
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (n2[mid] < node) lo = mid + 1;
+        else hi = mid;
+    }
+    if (lo >= fv2_count[f] || n2[lo] != node) return;
+    const int32_t* s1 = fv1_start + (long long)f * (node_cap + 1);
+    const int32_t* s2 = fv2_start + (long long)f * (node_cap + 1);
+    const int32_t* l1 = fv1_feat + (long long)f * cap + s1[j];
+    const int32_t* l2 = fv2_feat + (long long)f * cap + s2[lo];
+    const int len1 = s1[j + 1] - s1[j], len2 = s2[lo + 1] - s2[lo];
+    for (int p = lane; p < len2; p += 64) taken[p] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const uint8_t* v1 = valid1 + (long long)f * cap;
+    const uint8_t* v2 = valid2 ? valid2 + (long long)f * cap : nullptr;
+    const uint8_t* d1f = desc1 + (long long)f * cap * 32;
+    const uint8_t* d2f = desc2 + (long long)f * cap * 32;
+    int32_t* m12 = matches12 + (long long)f * cap;
+    int32_t* m21 = matches21 + (long long)f * cap;
+    int count = 0;
+    for (int i1 = 0; i1 < len1; i1++) {
+        const int idx1 = l1[i1];
+        if (!v1[idx1]) continue;  // no map point / bad map point
+        const uint4* q = (const uint4*)(d1f + (long long)idx1 * 32);
+        const uint4 q0 = q[0], q1 = q[1];
+        unsigned long long k1 = 0xffffffffffffffffull, k2 = 0xffffffffffffffffull;
+        for (int p = lane; p < len2; p += 64) {
+            const int idx2 = l2[p];
+            if (taken[p] || (v2 && !v2[idx2])) continue;
+            const uint4* t = (const uint4*)(d2f + (long long)idx2 * 32);
+            const uint4 a = t[0], b = t[1];
+            const int d = __popc(a.x ^ q0.x) + __popc(a.y ^ q0.y) + __popc(a.z ^ q0.z) + __popc(a.w ^ q0.w) +
+                          __popc(b.x ^ q1.x) + __popc(b.y ^ q1.y) + __popc(b.z ^ q1.z) + __popc(b.w ^ q1.w);
+            const unsigned long long key = ((unsigned long long)d << 32) | (unsigned)p;
+            k2 = min(max(k1, key), k2);
+            k1 = min(k1, key);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long p1 = __shfl_xor(k1, o), p2 = __shfl_xor(k2, o);
+            const unsigned long long mn = min(k1, p1), mx = max(k1, p1);
+            k2 = min(mx, min(k2, p2));
+            k1 = mn;
+        }
+        if (k1 == 0xffffffffffffffffull) continue;
+        const int bestDist1 = (int)(k1 >> 32), pos = (int)(k1 & 0xffffffffu);
+        const float fBest2 = k2 == 0xffffffffffffffffull ? (float)INT_MAX : (float)(int)(k2 >> 32);
+        const bool low = th_inclusive ? bestDist1 <= BOW_TH_LOW : bestDist1 < BOW_TH_LOW;  // :235 / :802
+        if (low && (float)bestDist1 < __fmul_rn(ratio, fBest2)) {                            // :237 / :804
+            if (lane == 0) {
+                const int idx2 = l2[pos];
+                m12[idx1] = idx2;
+                m21[idx2] = idx1;
+                taken[pos] = 1;
+            }
+            count++;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    }
+    if (lane == 0 && count) atomicAdd(&nmatches[f], count);
+}
+
+__device__ __forceinline__ float bow_round_half_away(float v) {
+    const float t = truncf(v);
+    return fabsf(__fsub_rn(v, t)) >= 0.5f ? (v < 0.f ? t - 1.f : t + 1.f) : t;
+}
+__device__ __forceinline__ int bow_rot_bin(float a1, float a2) {
+    const float factor = 1.0f / BOW_HISTO_LENGTH;
+    float rot = __fsub_rn(a1, a2);
+    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+    int bin = (int)bow_round_half_away(__fmul_rn(rot, factor));
+    if (bin == BOW_HISTO_LENGTH) bin = 0;
+    return bin;
+}
+
+// Rotation histogram over all matches, ComputeThreeMaxima (src/ORBmatcher.cc:1759-1800), removal of
+// the matches outside the kept bins.  One workgroup per frame pair.
+__global__ __launch_bounds__(256) void k_bow_rot_filter(const KpDevB* __restrict__ kp1, const KpDevB* __restrict__ kp2,
+                                                        const int32_t* __restrict__ n1_arr, int cap,
+                                                        int32_t* __restrict__ matches12, int32_t* __restrict__ matches21,
+                                                        int32_t* __restrict__ nmatches) {
+    __shared__ int hist[32];
+    __shared__ int removed;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int n1 = min(max(n1_arr[f], 0), cap);
+    if (tid < 32) hist[tid] = 0;
+    if (tid == 0) removed = 0;
+    __syncthreads();
+    const KpDevB* k1 = kp1 + (long long)f * cap;
+    const KpDevB* k2 = kp2 + (long long)f * cap;
+    int32_t* m12 = matches12 + (long long)f * cap;
+    int32_t* m21 = matches21 + (long long)f * cap;
+    for (int i = tid; i < n1; i += 256)
+        if (m12[i] >= 0) atomicAdd(&hist[bow_rot_bin(k1[i].angle, k2[m12[i]].angle)], 1);
+    __syncthreads();
+    int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+    for (int i = 0; i < BOW_HISTO_LENGTH; i++) {
+        const int sz = hist[i];
+        if (sz > max1) {
+            max3 = max2; max2 = max1; max1 = sz;
+            ind3 = ind2; ind2 = ind1; ind1 = i;
+        } else if (sz > max2) {
+            max3 = max2; max2 = sz;
+            ind3 = ind2; ind2 = i;
+        } else if (sz > max3) {
+            max3 = sz;
+            ind3 = i;
+        }
+    }
+    if ((float)max2 < 0.1f * (float)max1) {
+        ind2 = -1;
+        ind3 = -1;
+    } else if ((float)max3 < 0.1f * (float)max1) {
+        ind3 = -1;
+    }
+    int mine = 0;
+    for (int i = tid; i < n1; i += 256) {
+        const int m = m12[i];
+        if (m >= 0) {
+            const int bin = bow_rot_bin(k1[i].angle, k2[m].angle);
+            if (bin != ind1 && bin != ind2 && bin != ind3) {
+                m12[i] = -1;
+                m21[m] = -1;
+                mine++;
+            }
+        }
+    }
+    if (mine) atomicAdd(&removed, mine);
+    __syncthreads();
+    if (tid == 0) nmatches[f] -= removed;
+}
+
+}  // namespace
+
+extern "C" {
+
+int orbhip_feature_vector_device(orbhip_matcher* m, const int32_t* d_node, const double* d_weight, const int32_t* d_n,
+                                 int batch, int cap, int node_cap, int32_t* d_fv_nodes, int32_t* d_fv_start,
+                                 int32_t* d_fv_feat, int32_t* d_fv_count) {
+    if (!m) return orb_fail(ORBHIP_EINVAL, "null matcher");
+    if (batch < 0 || cap < 1 || node_cap < 1) return orb_fail(ORBHIP_EINVAL, "bad size");
+    if (cap > ORBHIP_FRAME_MAX_KEYPOINTS) return orb_fail(ORBHIP_ECAP, "cap %d > %d features per frame", cap, ORBHIP_FRAME_MAX_KEYPOINTS);
+    if (batch == 0) return ORBHIP_OK;
+    if (!d_node || !d_weight || !d_n || !d_fv_nodes || !d_fv_start || !d_fv_feat || !d_fv_count)
+        return orb_fail(ORBHIP_EINVAL, "null buffer");
+    HIPCHK(hipSetDevice(m->device));
+    (void)hipGetLastError();
+    int np2 = 64;
+    while (np2 < cap) np2 <<= 1;
+    const size_t lds = sizeof(unsigned long long) * (size_t)np2;
+    HIPCHK(hipFuncSetAttribute((const void*)k_feature_vector, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_feature_vector, dim3(batch), dim3(FV_THREADS), lds, m->stream, d_node, d_weight, d_n, cap, node_cap,
+                       d_fv_nodes, d_fv_start, d_fv_feat, d_fv_count, m->d_err);
+    HIPCHK(hipGetLastError());
+    return ORBHIP_OK;
+}
+
+int orbhip_search_by_bow_device(orbhip_matcher* m, const OrbKeypoint* d_kp1, const uint8_t* d_desc1, const int32_t* d_n1,
+                                const uint8_t* d_valid1, const int32_t* d_fv1_nodes, const int32_t* d_fv1_start,
+                                const int32_t* d_fv1_feat, const int32_t* d_fv1_count, const OrbKeypoint* d_kp2,
+                                const uint8_t* d_desc2, const int32_t* d_n2, const uint8_t* d_valid2,
+                                const int32_t* d_fv2_nodes, const int32_t* d_fv2_start, const int32_t* d_fv2_feat,
+                                const int32_t* d_fv2_count, int batch, int cap, int node_cap, float nnratio,
+                                int check_orientation, int th_low_inclusive, int32_t* d_matches12, int32_t* d_matches21,
+                                int32_t* d_nmatches) {
+    if (!m) return orb_fail(ORBHIP_EINVAL, "null matcher");
+    if (batch < 0 || cap < 1 || node_cap < 1) return orb_fail(ORBHIP_EINVAL, "bad size");
+    if (cap > ORBHIP_FRAME_MAX_KEYPOINTS) return orb_fail(ORBHIP_ECAP, "cap %d > %d features per frame", cap, ORBHIP_FRAME_MAX_KEYPOINTS);
+    if (batch == 0) return ORBHIP_OK;
+    if (!d_kp1 || !d_desc1 || !d_n1 || !d_valid1 || !d_fv1_nodes || !d_fv1_start || !d_fv1_feat || !d_fv1_count || !d_kp2 ||
+        !d_desc2 || !d_n2 || !d_fv2_nodes || !d_fv2_start || !d_fv2_feat || !d_fv2_count || !d_matches12 || !d_matches21 ||
+        !d_nmatches)
+        return orb_fail(ORBHIP_EINVAL, "null buffer");
+    HIPCHK(hipSetDevice(m->device));
+    (void)hipGetLastError();
+    HIPCHK(hipEventRecord(m->ev0, m->stream));
+    HIPCHK(hipMemsetAsync(d_matches12, 0xff, sizeof(int32_t) * (size_t)batch * cap, m->stream));
+    HIPCHK(hipMemsetAsync(d_matches21, 0xff, sizeof(int32_t) * (size_t)batch * cap, m->stream));
+    HIPCHK(hipMemsetAsync(d_nmatches, 0, sizeof(int32_t) * (size_t)batch, m->stream));
+    hipLaunchKernelGGL(k_bow_match, dim3(node_cap, batch), dim3(64), 0, m->stream, d_desc1, d_valid1, d_fv1_nodes, d_fv1_start,
+                       d_fv1_feat, d_fv1_count, d_desc2, d_valid2, d_fv2_nodes, d_fv2_start, d_fv2_feat, d_fv2_count, cap,
+                       node_cap, nnratio, th_low_inclusive, d_matches12, d_matches21, d_nmatches);
+    if (check_orientation)
+        hipLaunchKernelGGL(k_bow_rot_filter, dim3(batch), dim3(256), 0, m->stream, (const KpDevB*)d_kp1, (const KpDevB*)d_kp2,
+                           d_n1, cap, d_matches12, d_matches21, d_nmatches);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(m->ev1, m->stream));
     return ORBHIP_OK;
 }
 

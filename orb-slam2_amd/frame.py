@@ -56,6 +56,37 @@ class FrameBatch:
         return cls(matcher, torch.from_numpy(kp).to(device), torch.from_numpy(de).to(device),
                    torch.from_numpy(n).to(device), bounds)
 
+    def ComputeBoW(self, voc, levelsup=4, node_cap=None):
+        """Frame::ComputeBoW / KeyFrame::ComputeBoW (src/Frame.cc:281-288, src/KeyFrame.cc:82-91) for every frame
+        of the batch: the vocabulary descent of all descriptors and the FeatureVector (mFeatVec) on the device.
+        Sets bow_word / bow_node / bow_weight [batch, cap] and the FeatureVector arrays fv_nodes [batch, node_cap],
+        fv_start [batch, node_cap + 1], fv_feat [batch, cap], fv_count [batch]."""
+        import torch
+        dev = self.n.device
+        b, cap = self.batch, self.cap
+        self.node_cap = int(node_cap or cap)
+        self.bow_word = torch.zeros((b, cap), dtype=torch.int32, device=dev)
+        self.bow_node = torch.zeros((b, cap), dtype=torch.int32, device=dev)
+        self.bow_weight = torch.zeros((b, cap), dtype=torch.float64, device=dev)
+        self.fv_nodes = torch.zeros((b, self.node_cap), dtype=torch.int32, device=dev)
+        self.fv_start = torch.zeros((b, self.node_cap + 1), dtype=torch.int32, device=dev)
+        self.fv_feat = torch.zeros((b, cap), dtype=torch.int32, device=dev)
+        self.fv_count = torch.zeros(b, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        # descriptors past a frame's count are transformed too (rows of zeros) and ignored by the FeatureVector
+        voc.transform_device(self._m, self.desc.data_ptr(), b * cap, levelsup, self.bow_word.data_ptr(),
+                             self.bow_node.data_ptr(), self.bow_weight.data_ptr())
+        _lib.check(_lib.lib().orbhip_feature_vector_device(
+            self._m._h, self.bow_node.data_ptr(), self.bow_weight.data_ptr(), self.n.data_ptr(), b, cap, self.node_cap,
+            self.fv_nodes.data_ptr(), self.fv_start.data_ptr(), self.fv_feat.data_ptr(), self.fv_count.data_ptr()))
+        self._m.synchronize()
+
+    def feature_vector(self, f):
+        """mFeatVec of frame f on the host: (nodes, start, features)."""
+        k = int(self.fv_count[f])
+        st = self.fv_start[f, :k + 1].cpu().numpy()
+        return self.fv_nodes[f, :k].cpu().numpy(), st, self.fv_feat[f, :st[-1] if k else 0].cpu().numpy()
+
     def grid(self, f):
         """(cell_start[3073], items) of frame f on the host; cell = ix*48 + iy."""
         cs = self.cell_start[f].cpu().numpy()

@@ -148,6 +148,29 @@ class ORBmatcher:
             self.mfNNratio, int(self.mbCheckOrientation), _p(m21), C.byref(nm)))
         return nm.value, m21[:len(kp2)].copy()
 
+    def SearchByBoW(self, F1, F2, valid1, valid2=None, kf_frame=False):
+        """ORBmatcher::SearchByBoW for every pair of two FrameBatch objects on which ComputeBoW has run.
+        kf_frame=False: SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) (src/ORBmatcher.cc:726-861), valid1 / valid2
+        uint8 CUDA tensors [batch, cap] (map point exists and is not bad).
+        kf_frame=True: SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (:158-295), F1 the keyframe, F2 the frame.
+        Returns (nmatches [batch], matches12 [batch, cap], matches21 [batch, cap]) int32 CUDA tensors."""
+        import torch
+        assert F1.batch == F2.batch and F1.cap == F2.cap and F1.node_cap == F2.node_cap
+        dev = F1.n.device
+        m12 = torch.empty((F1.batch, F1.cap), dtype=torch.int32, device=dev)
+        m21 = torch.empty((F1.batch, F1.cap), dtype=torch.int32, device=dev)
+        nm = torch.empty(F1.batch, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        _lib.check(self._L.orbhip_search_by_bow_device(
+            self._h, F1.kp.data_ptr(), F1.desc.data_ptr(), F1.n.data_ptr(), valid1.data_ptr(), F1.fv_nodes.data_ptr(),
+            F1.fv_start.data_ptr(), F1.fv_feat.data_ptr(), F1.fv_count.data_ptr(), F2.kp.data_ptr(), F2.desc.data_ptr(),
+            F2.n.data_ptr(), None if (kf_frame or valid2 is None) else valid2.data_ptr(), F2.fv_nodes.data_ptr(),
+            F2.fv_start.data_ptr(), F2.fv_feat.data_ptr(), F2.fv_count.data_ptr(), F1.batch, F1.cap, F1.node_cap,
+            self.mfNNratio, int(self.mbCheckOrientation), int(bool(kf_frame)), m12.data_ptr(), m21.data_ptr(),
+            nm.data_ptr()))
+        self.synchronize()
+        return nm, m12, m21
+
     def ComputeDistinctiveDescriptors(self, desc, start):
         """MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:191-256) for many map points:
         desc [total, 32] u8 and start [npoints + 1] i32 CUDA tensors (observations of point p are rows

@@ -69,3 +69,76 @@ def test_l1_score_of_two_views(orb, orbref, synth):
     s = voc.score_l1(va, vb)
     assert s == orbref.bow_score_l1(ra, rb)
     assert 0.0 < s < 1.0 and voc.score_l1(va, va) == pytest.approx(1.0)
+
+
+def _frames(orbref, rng, desc_pool, sizes):
+    out = []
+    for n in sizes:
+        kp = np.zeros(n, orbref.KP_DTYPE)
+        kp["x"], kp["y"] = rng.uniform(0, 640, n), rng.uniform(0, 480, n)
+        kp["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+        out.append((kp, _features(rng, desc_pool, n) if n else np.zeros((0, 32), np.uint8)))
+    return out
+
+
+def _second_view(rng, kp, de, rot=25.0):
+    keep = rng.random(len(kp)) > 0.1
+    kp2, de2 = kp[keep].copy(), de[keep].copy()
+    kp2["angle"] = np.mod(kp2["angle"] - np.float32(rot) + rng.normal(0, 6, len(kp2)).astype(np.float32), 360).astype(np.float32)
+    wild = rng.random(len(kp2)) < 0.1
+    kp2["angle"][wild] = rng.uniform(0, 360, int(wild.sum())).astype(np.float32)
+    for i in range(len(kp2)):
+        for _ in range(rng.integers(0, 6)):
+            de2[i, rng.integers(0, 32)] ^= np.uint8(1 << rng.integers(0, 8))
+    p = rng.permutation(len(kp2))
+    return kp2[p], de2[p]
+
+
+@pytest.mark.parametrize("kf_frame", [False, True])
+@pytest.mark.parametrize("ori", [True, False])
+def test_search_by_bow(orb, orbref, synth, kf_frame, ori):
+    import torch
+    k, L, levelsup = 10, 4, 2   # FeatureVector nodes at level 2: up to 100 nodes
+    parent, desc, weight = synth.synth_vocabulary(k, L, seed=17)
+    voc = orb.ORBVocabulary(parent, desc, weight, L)
+    ref = orbref.RefVocabulary(parent, desc, weight, L)
+    rng = np.random.default_rng(23)
+    fr1 = _frames(orbref, rng, desc, [0, 3, 200, 1500, 2000])
+    fr2 = [_second_view(rng, kp, de) for kp, de in fr1]
+    fr2[2] = (fr2[2][0][:0], fr2[2][1][:0])  # an empty second frame
+    m = orb.ORBmatcher(0.8 if not kf_frame else 0.7, ori)
+    cap = max(max(len(a[0]), len(b[0])) for a, b in zip(fr1, fr2)) or 1
+    F1 = orb.FrameBatch.from_host(m, [a for a, _ in fr1], [b for _, b in fr1], [0, 0, 640, 480], cap=cap)
+    F2 = orb.FrameBatch.from_host(m, [a for a, _ in fr2], [b for _, b in fr2], [0, 0, 640, 480], cap=cap)
+    F1.ComputeBoW(voc, levelsup, node_cap=256)
+    F2.ComputeBoW(voc, levelsup, node_cap=256)
+    v1 = np.zeros((len(fr1), cap), np.uint8)
+    v2 = np.zeros((len(fr1), cap), np.uint8)
+    for f in range(len(fr1)):
+        v1[f, :len(fr1[f][0])] = rng.random(len(fr1[f][0])) < 0.8
+        v2[f, :len(fr2[f][0])] = rng.random(len(fr2[f][0])) < 0.9
+    nm, m12, m21 = m.SearchByBoW(F1, F2, torch.from_numpy(v1).cuda(), torch.from_numpy(v2).cuda(), kf_frame=kf_frame)
+    nm, m12, m21 = nm.cpu().numpy(), m12.cpu().numpy(), m21.cpu().numpy()
+    total = 0
+    for f in range(len(fr1)):
+        (kp1, de1), (kp2, de2) = fr1[f], fr2[f]
+        _, fv1 = ref.transform(de1, levelsup)
+        _, fv2 = ref.transform(de2, levelsup)
+        # the device FeatureVector equals the reference's
+        for F, fv, nfeat in ((F1, fv1, len(kp1)), (F2, fv2, len(kp2))):
+            dn, ds, dfeat = F.feature_vector(f)
+            assert np.array_equal(dn, fv[0]) and np.array_equal(ds, fv[1]) and np.array_equal(dfeat, fv[2]), "FeatureVector %d" % f
+        if kf_frame:
+            rn, rF = orbref.search_by_bow_kf_frame(kp1, de1, v1[f, :len(kp1)], fv1, kp2, de2, fv2, m.mfNNratio, ori)
+            assert np.array_equal(rF, m21[f, :len(kp2)]), "pair %d vpMapPointMatches" % f
+        else:
+            rn, r12 = orbref.search_by_bow_kf_kf(kp1, de1, v1[f, :len(kp1)], fv1, kp2, de2, v2[f, :len(kp2)], fv2,
+                                                 m.mfNNratio, ori)
+            assert np.array_equal(r12, m12[f, :len(kp1)]), "pair %d vpMatches12" % f
+        assert rn == nm[f], "pair %d nmatches" % f
+        # the two output arrays describe the same matching
+        for i1 in np.nonzero(m12[f] >= 0)[0]:
+            assert m21[f, m12[f, i1]] == i1
+        assert (m21[f] >= 0).sum() == (m12[f] >= 0).sum() == nm[f]
+        total += rn
+    assert total > 300

@@ -160,3 +160,28 @@ def test_bow_transform_by_hand(orbref):
     binary = orbref.RefVocabulary(parent, desc, weight, 2, weighting=3, scoring=5)
     (bw, bv), _ = binary.transform(f, 1)
     assert list(bw) == [0, 1] and list(bv) == [1.5, 2.0]           # addIfNotExist, no normalisation
+
+
+def test_search_by_bow_by_hand(orbref):
+    """Two nodes.  Node 5: keyframe features [0, 1] vs frame features [0, 1]; node 9: [2] vs [2].
+    Feature 0 of the keyframe takes frame feature 1 (distance 2 vs 12); feature 1 then sees only frame
+    feature 0 (a single candidate: second best INT_MAX) at distance 20 -> accepted by the KeyFrame/Frame
+    form (<= TH_LOW), rejected by the KeyFrame/KeyFrame form (< TH_LOW)."""
+    kp = kps(orbref, [(10, 10, 0, 0.0)] * 3)
+    d1 = np.stack([bits(0), bits(0), bits(7)])
+    d2 = np.stack([bits(12) if False else bits(20), bits(2), bits(9)])
+    # distances: kf0-f0 = 20, kf0-f1 = 2; kf1-f0 = 20 (f1 taken); kf2-f2 = 2
+    fv = (np.array([5, 9], np.int32), np.array([0, 2, 3], np.int32), np.array([0, 1, 2], np.int32))
+    ones = np.ones(3, np.uint8)
+    n, mF = orbref.search_by_bow_kf_frame(kp, d1, ones, fv, kp, d2, fv, 0.7, False)
+    assert n == 3 and list(mF) == [1, 0, 2]
+    n, m12 = orbref.search_by_bow_kf_kf(kp, d1, ones, fv, kp, d2, ones, fv, 0.7, False)
+    assert n == 2 and list(m12) == [1, -1, 2]
+    # a keyframe feature without a good map point is skipped; a bad map point in keyframe 2 is skipped
+    n, m12 = orbref.search_by_bow_kf_kf(kp, d1, np.array([0, 1, 1], np.uint8), fv, kp, d2, np.array([1, 0, 1], np.uint8), fv,
+                                        0.7, False)
+    assert n == 1 and list(m12) == [-1, -1, 2]
+    # nodes present in only one FeatureVector are skipped by the lower_bound stepping
+    fvb = (np.array([5, 7, 9], np.int32), np.array([0, 1, 2, 3], np.int32), np.array([1, 0, 2], np.int32))
+    n, m12 = orbref.search_by_bow_kf_kf(kp, d1, ones, fv, kp, d2, ones, fvb, 0.7, False)
+    assert n == 2 and list(m12) == [1, -1, 2]  # node 5 of keyframe 2 now holds only feature 1
