@@ -215,7 +215,9 @@ def main():
 
         # ---- CPU baseline on a bounded sample of the same frames + parity of that sample --------
         threads = max(1, min(16, os.cpu_count() or 1))
-        cpu_fps, ref_results = cpu_baseline(wl.host, args.features, threads, args.cpu_sample)
+        if world > 1:  # the CPU baseline and the extra legs belong to the N = 1 run; the other ranks are waiting
+            args.cpu_sample, args.no_extra = 0, True
+        cpu_fps, ref_results = cpu_baseline(wl.host, args.features, threads, args.cpu_sample) if args.cpu_sample > 0 else (0.0, [])
         kp = wl.d_kp.cpu().numpy().view(np.uint32)
         desc = wl.d_desc.cpu().numpy()
         ncount = wl.d_n.cpu().numpy()
@@ -225,7 +227,7 @@ def main():
             same = ncount[i] == n and np.array_equal(kp[i, :n].reshape(-1), rkp.view(np.uint32).reshape(-1)) \
                 and np.array_equal(desc[i, :n], rdesc)
             mism += 0 if same else 1
-        cpu = {"value": round(cpu_fps, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+        cpu = None if not ref_results else {"value": round(cpu_fps, 3), "unit": "frames/s", "cores": threads, "kind": "port",
                "sample": "%d of the %d frames of this workload (%dx%d, %d features), one oracle extractor per thread"
                          % (len(ref_results), args.batch, args.width, args.height, args.features),
                "parity_frames_checked": len(ref_results), "parity_frames_mismatching": mism}

@@ -739,15 +739,20 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
                     if (y < ph) {
                         uint32_t o = ctr[(i - 3) % 7];
                         if (y >= ORB_EDGE && y < L.h + ORB_EDGE && colmask) {
-                            uint32_t bl = 0;
+                            // (sum + 2^15) >> 16 saturated to 255: the rounding constant rides on the centre tap's
+                            // multiply-add, the saturation is a clamp to 2^24 - 1, and byte 2 of each clamped sum
+                            // is the pixel (two byte permutes assemble the four of them)
+                            uint32_t acc[4];
 #pragma unroll
                             for (int j = 0; j < 4; j++) {
-                                const uint32_t acc = (uint32_t)t0 * (h[(i - 6) % 7][j] + h[i % 7][j]) +
-                                                     (uint32_t)t1 * (h[(i - 5) % 7][j] + h[(i - 1) % 7][j]) +
-                                                     (uint32_t)t2 * (h[(i - 4) % 7][j] + h[(i - 2) % 7][j]) +
-                                                     (uint32_t)t3 * h[(i - 3) % 7][j];
-                                bl |= min((acc + 32768u) >> 16, 255u) << (8 * j);
+                                uint32_t a = (uint32_t)t3 * h[(i - 3) % 7][j] + 32768u;
+                                a += (uint32_t)t0 * (h[(i - 6) % 7][j] + h[i % 7][j]);
+                                a += (uint32_t)t1 * (h[(i - 5) % 7][j] + h[(i - 1) % 7][j]);
+                                a += (uint32_t)t2 * (h[(i - 4) % 7][j] + h[(i - 2) % 7][j]);
+                                acc[j] = min(a, 0xffffffu);
                             }
+                            const uint32_t bl = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u) |
+                                                __builtin_amdgcn_perm(acc[3], acc[2], 0x06020c0cu);
                             o = (bl & colmask) | (o & ~colmask);
                         }
                         *(uint32_t*)(dst + (long long)y * stride + px0) = o;

@@ -14,7 +14,7 @@
 //      reference's state (vMatchedDistance / vnMatches21 / vnMatches12) in LDS; the candidates of
 //      one keypoint are examined by the 64 lanes at once and reduced with the ordered-minimum rule
 //      (first candidate in list order attaining the minimum; second order statistic with
-//      multiplicity); the next keypoint's candidates are in flight while the current one is resolved;
+//      multiplicity); the candidate lists of runs of consecutive keypoints are staged in LDS first;
 //   3. rotation histogram, ComputeThreeMaxima (src/ORBmatcher.cc:1759-1800) and the final filter.
 // All float expressions are evaluated operation by operation in fp32 (no contraction), as the
 // reference's are.
@@ -36,6 +36,7 @@ namespace {
 #define TH_LOW 20
 #define NONE16 0xffffu
 #define KEY_NONE 0xffffffffffffffffull
+#define RB_CAP 4096  // candidate entries staged in LDS per run of the resolution kernel
 
 struct GridGeom {
     float min_x, min_y;  // (float)mnMinX, (float)mnMinY
@@ -363,7 +364,8 @@ __device__ inline uint32_t three_maxima_mask(const int* hist) {
     return mask;
 }
 
-// mode MODE_SEARCH_INIT or MODE_WINDOW.  LDS: four uint16 arrays of cap entries + histogram.
+// mode MODE_SEARCH_INIT or MODE_WINDOW.  LDS: four uint16 arrays of cap entries, the candidate
+// run buffer (RB_CAP entries, at byte offset 8 * cap) and the histogram.
 template <int MODE>
 __global__ __launch_bounds__(64) void k_resolve(const KpDev* __restrict__ kp1, const int32_t* __restrict__ n1_arr,
                                                 const KpDev* __restrict__ kp2, const int32_t* __restrict__ n2_arr, int cap,
@@ -392,30 +394,36 @@ __global__ __launch_bounds__(64) void k_resolve(const KpDev* __restrict__ kp1, c
     const uint32_t* fp = pairs + frame_base[f];
     int nmatches = 0;
 
+    // Candidate lists are consumed in runs: the lists of as many consecutive keypoints as fit are copied
+    // to LDS with one coalesced pass, so that the sequential walk below never waits on global memory.
+    uint32_t* cbuf = (uint32_t*)(lds16 + 4 * cap);
     for (int c0 = 0; c0 < n1; c0 += 64) {
         // starts of 64 keypoints at once; lane j holds those of keypoint c0 + j
         const int ci = min(c0 + lane, n1);
         const int my_s = st[ci], my_e = st[min(ci + 1, cap)];
         const int chunk = min(64, n1 - c0);
-        // candidates of the first keypoint of the chunk
-        int s = __shfl(my_s, 0), e = __shfl(c0 + 1 <= n1 ? my_e : my_s, 0);
-        uint32_t cur = (s + lane < e) ? fp[s + lane] : 0u;
-        for (int j = 0; j < chunk; j++) {
-            const int i1 = c0 + j;
-            // prefetch the next keypoint's first 64 candidates
-            int ns = 0, ne = 0;
-            uint32_t nxt = 0u;
-            if (j + 1 < chunk) {
-                ns = __shfl(my_s, j + 1);
-                ne = __shfl(my_e, j + 1);
-                if (ns + lane < ne) nxt = fp[ns + lane];
+        int j0 = 0;
+        while (j0 < chunk) {
+            const int S = __shfl(my_s, j0);
+            // keypoints j0 .. j0 + q - 1 fit the buffer together (list ends are monotone)
+            const unsigned long long fit = __ballot(lane >= j0 && lane < chunk && my_e - S <= RB_CAP);
+            const int q = __popcll(fit);
+            const bool buffered = q > 0;
+            const int jn = buffered ? j0 + q : j0 + 1;
+            if (buffered) {
+                const int E = __shfl(my_e, jn - 1);
+                for (int p = S + lane; p < E; p += 64) cbuf[p - S] = fp[p];
+                wave_fence();
             }
-            if (s < e) {
+            for (int j = j0; j < jn; j++) {
+                const int i1 = c0 + j;
+                const int s = __shfl(my_s, j), e = __shfl(my_e, j);
+                if (s >= e) continue;
                 unsigned long long k1 = KEY_NONE, k2 = KEY_NONE;
                 for (int b = s; b < e; b += 64) {
                     const int p = b + lane;
-                    const uint32_t pr = (b == s) ? cur : (p < e ? fp[p] : 0u);
                     if (p < e) {
+                        const uint32_t pr = buffered ? cbuf[p - S] : fp[p];
                         const uint32_t i2 = pr & 0xffffu, dist = pr >> 16;
                         bool skip;
                         if (MODE == MODE_SEARCH_INIT) skip = (uint32_t)matchedDist[i2] <= dist;  // :648
@@ -430,38 +438,36 @@ __global__ __launch_bounds__(64) void k_resolve(const KpDev* __restrict__ kp1, c
                 }
                 unsigned long long b1, b2;
                 wave_two_smallest(k1, k2, b1, b2);
-                if (b1 != KEY_NONE) {
-                    const int bestDist = (int)(b1 >> 32), bestIdx2 = (int)(b1 & 0xffffu);
-                    const float fBest2 = b2 == KEY_NONE ? (float)INT_MAX : (float)(int)(b2 >> 32);
-                    bool accept;
-                    if (MODE == MODE_SEARCH_INIT)
-                        accept = bestDist <= TH_LOW && (float)bestDist < __fmul_rn(fBest2, ratio);  // :663-665
-                    else
-                        accept = (float)bestDist <= __fmul_rn(fBest2, ratio) && bestDist <= TH_HIGH;  // :487
-                    if (accept) {
-                        if (MODE == MODE_SEARCH_INIT) {
-                            const uint32_t old = m21[bestIdx2];
-                            if (old != NONE16) nmatches--;
-                            wave_fence();
-                            if (lane == 0) {
-                                if (old != NONE16) m12[old] = NONE16;
-                                m12[i1] = (uint16_t)bestIdx2;
-                                m21[bestIdx2] = (uint16_t)i1;
-                                matchedDist[bestIdx2] = (uint16_t)bestDist;
-                                partner[i1] = (uint16_t)bestIdx2;
-                            }
-                        } else {
-                            wave_fence();
-                            if (lane == 0) m21[bestIdx2] = (uint16_t)i1;
-                        }
-                        nmatches++;
+                if (b1 == KEY_NONE) continue;
+                const int bestDist = (int)(b1 >> 32), bestIdx2 = (int)(b1 & 0xffffu);
+                const float fBest2 = b2 == KEY_NONE ? (float)INT_MAX : (float)(int)(b2 >> 32);
+                bool accept;
+                if (MODE == MODE_SEARCH_INIT)
+                    accept = bestDist <= TH_LOW && (float)bestDist < __fmul_rn(fBest2, ratio);  // :663-665
+                else
+                    accept = (float)bestDist <= __fmul_rn(fBest2, ratio) && bestDist <= TH_HIGH;  // :487
+                if (accept) {
+                    if (MODE == MODE_SEARCH_INIT) {
+                        const uint32_t old = m21[bestIdx2];
+                        if (old != NONE16) nmatches--;
                         wave_fence();
+                        if (lane == 0) {
+                            if (old != NONE16) m12[old] = NONE16;
+                            m12[i1] = (uint16_t)bestIdx2;
+                            m21[bestIdx2] = (uint16_t)i1;
+                            matchedDist[bestIdx2] = (uint16_t)bestDist;
+                            partner[i1] = (uint16_t)bestIdx2;
+                        }
+                    } else {
+                        wave_fence();
+                        if (lane == 0) m21[bestIdx2] = (uint16_t)i1;
                     }
+                    nmatches++;
+                    wave_fence();
                 }
             }
-            s = ns;
-            e = ne;
-            cur = nxt;
+            wave_fence();  // the buffer is reused by the next run
+            j0 = jn;
         }
     }
     wave_fence();
@@ -621,7 +627,7 @@ int run_matcher(orbhip_matcher* m, int mode, const OrbKeypoint* d_kp1, const uin
     HIPCHK(hipStreamSynchronize(m->stream));  // `base` is a stack-lifetime host buffer
     hipLaunchKernelGGL(k_area_fill, qgrid, dim3(256), 0, m->stream, s, (const KpDev*)d_kp2, d_cell_start2, d_cell_items2, cap,
                        gg, starts, (int32_t*)nullptr, 0, m->d_err, d_desc1, d_desc2, d_base, pairs);
-    const size_t lds = sizeof(uint16_t) * 4 * (size_t)cap;
+    const size_t lds = sizeof(uint16_t) * 4 * (size_t)cap + sizeof(uint32_t) * RB_CAP;
     if (mode == MODE_SEARCH_INIT) {
         HIPCHK(hipFuncSetAttribute((const void*)k_resolve<MODE_SEARCH_INIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_resolve<MODE_SEARCH_INIT>, dim3(batch), dim3(64), lds, m->stream, (const KpDev*)d_kp1, d_n1,
