@@ -127,40 +127,57 @@ struct AreaQuery {
     bool active;
 };
 
-template <class Visit>
-__device__ __forceinline__ void for_each_in_area(const GridGeom& gg, const KpDev* __restrict__ kp,
-                                                 const int32_t* __restrict__ cs, const int32_t* __restrict__ items,
-                                                 const AreaQuery& q, Visit visit) {
-    const float fx = __fsub_rn(q.x, gg.min_x), fy = __fsub_rn(q.y, gg.min_y);
-    int nMinCellX = (int)floorf(__fmul_rn(__fsub_rn(fx, q.r), gg.inv_w));
-    nMinCellX = max(0, nMinCellX);
-    if (nMinCellX >= GRID_COLS) return;
-    int nMaxCellX = (int)ceilf(__fmul_rn(__fadd_rn(fx, q.r), gg.inv_w));
-    nMaxCellX = min(GRID_COLS - 1, nMaxCellX);
-    if (nMaxCellX < 0) return;
-    int nMinCellY = (int)floorf(__fmul_rn(__fsub_rn(fy, q.r), gg.inv_h));
-    nMinCellY = max(0, nMinCellY);
-    if (nMinCellY >= GRID_ROWS) return;
-    int nMaxCellY = (int)ceilf(__fmul_rn(__fadd_rn(fy, q.r), gg.inv_h));
-    nMaxCellY = min(GRID_ROWS - 1, nMaxCellY);
-    if (nMaxCellY < 0) return;
+// Sixteen lanes enumerate one query together: every lane of the group takes one item of the
+// column's run per step, the group's slice of the wave ballot gives the count and the ordered
+// position of each hit.  FILL = false only counts; FILL = true calls emit(i2, position) for every
+// hit, positions counting from `o` in the reference's order.  All lanes of the wave must call this
+// together (inactive queries included).  Returns the number of hits of the lane's group.
+#define AREA_LPQ 16
+template <bool FILL, class Emit>
+__device__ __forceinline__ int area_group(const GridGeom& gg, const KpDev* __restrict__ kp, const int32_t* __restrict__ cs,
+                                          const int32_t* __restrict__ items, const AreaQuery& q, int li, int o, Emit emit) {
+    int nMinCellX = 0, nMaxCellX = -1, nMinCellY = 0, nMaxCellY = -1;
+    if (q.active) {
+        const float fx = __fsub_rn(q.x, gg.min_x), fy = __fsub_rn(q.y, gg.min_y);
+        nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(fx, q.r), gg.inv_w)));
+        nMaxCellX = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(fx, q.r), gg.inv_w)));
+        nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(fy, q.r), gg.inv_h)));
+        nMaxCellY = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(fy, q.r), gg.inv_h)));
+        // "if(nMinCellX>=FRAME_GRID_COLS) return" ... "if(nMaxCellY<0) return": empty ranges below
+        if (nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0) nMaxCellX = nMinCellX - 1;
+        if (nMinCellY > nMaxCellY) nMaxCellX = nMinCellX - 1;
+    }
     const bool bCheckLevels = !(q.min_level == -1 && q.max_level == -1);
     const bool bSameLevel = bCheckLevels && q.min_level == q.max_level;
-    for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
-        if (nMinCellY > nMaxCellY) continue;
-        const int j0 = cs[ix * GRID_ROWS + nMinCellY], j1 = cs[ix * GRID_ROWS + nMaxCellY + 1];
-        for (int j = j0; j < j1; j++) {
-            const int i2 = items[j];
-            const KpDev& k = kp[i2];
-            if (bCheckLevels && !bSameLevel) {
-                if (k.octave < q.min_level || k.octave > q.max_level) continue;
-            } else if (bSameLevel) {
-                if (k.octave != q.min_level) continue;
+    const int shift = (int)(threadIdx.x & 63u & ~(AREA_LPQ - 1));  // first lane of the group inside the wave
+    int hits = 0;
+    for (int ix = nMinCellX; __ballot(ix <= nMaxCellX); ix++) {
+        int j0 = 0, j1 = 0;
+        if (ix <= nMaxCellX) {
+            j0 = cs[ix * GRID_ROWS + nMinCellY];
+            j1 = cs[ix * GRID_ROWS + nMaxCellY + 1];
+        }
+        for (int base = j0; __ballot(base < j1); base += AREA_LPQ) {
+            const int j = base + li;
+            bool hit = false;
+            int i2 = 0;
+            if (j < j1) {
+                i2 = items[j];
+                const KpDev& k = kp[i2];
+                hit = true;
+                if (bCheckLevels && !bSameLevel) {
+                    if (k.octave < q.min_level || k.octave > q.max_level) hit = false;
+                } else if (bSameLevel) {
+                    if (k.octave != q.min_level) hit = false;
+                }
+                if (fabsf(__fsub_rn(k.x, q.x)) > q.r || fabsf(__fsub_rn(k.y, q.y)) > q.r) hit = false;
             }
-            if (fabsf(__fsub_rn(k.x, q.x)) > q.r || fabsf(__fsub_rn(k.y, q.y)) > q.r) continue;
-            visit(i2);
+            const uint32_t slice = (uint32_t)(__ballot(hit) >> shift) & ((1u << AREA_LPQ) - 1u);
+            if (FILL && hit) emit(i2, o + hits + __popc(slice & ((1u << li) - 1u)));
+            hits += __popc(slice);
         }
     }
+    return hits;
 }
 
 // How the queries of a frame are defined.
@@ -216,14 +233,15 @@ __device__ __forceinline__ AreaQuery make_query(const QuerySource& s, int f, int
 __global__ __launch_bounds__(256) void k_area_count(QuerySource s, const KpDev* __restrict__ kp2, const int32_t* __restrict__ cell_start,
                                                     const int32_t* __restrict__ cell_items, int cap2, GridGeom gg,
                                                     int32_t* __restrict__ counts) {
-    const int i = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
-    if (i >= s.nq) return;
-    const AreaQuery q = make_query(s, f, i);
-    int c = 0;
-    if (q.active)
-        for_each_in_area(gg, kp2 + (long long)f * cap2, cell_start + (long long)f * (GRID_CELLS + 1),
-                         cell_items + (long long)f * cap2, q, [&](int) { c++; });
-    counts[(long long)f * (s.nq + 1) + i] = c;
+    const int i = (blockIdx.x * 256 + threadIdx.x) / AREA_LPQ, li = threadIdx.x % AREA_LPQ, f = blockIdx.y;
+    AreaQuery q;
+    q.active = false;
+    q.x = q.y = q.r = 0.f;
+    q.min_level = q.max_level = -1;
+    if (i < s.nq) q = make_query(s, f, i);
+    const int c = area_group<false>(gg, kp2 + (long long)f * cap2, cell_start + (long long)f * (GRID_CELLS + 1),
+                                    cell_items + (long long)f * cap2, q, li, 0, [](int, int) {});
+    if (i < s.nq && li == 0) counts[(long long)f * (s.nq + 1) + i] = c;
 }
 
 // In-place exclusive scan of the nq counts of every frame (one workgroup per frame); entry nq
@@ -259,12 +277,6 @@ __global__ __launch_bounds__(256) void k_scan_counts(int32_t* __restrict__ count
     }
 }
 
-__device__ __forceinline__ int hamming32(const uint4* __restrict__ a, const uint4* __restrict__ b) {
-    const uint4 a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
-    return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) +
-           __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
-}
-
 // Fill pass.  out_idx (explicit queries): indices only, frame f at f*out_cap, overflow flagged.
 // out_pairs (matchers): (distance << 16 | i2) at frame_base[f] + start.
 __global__ __launch_bounds__(256) void k_area_fill(QuerySource s, const KpDev* __restrict__ kp2, const int32_t* __restrict__ cell_start,
@@ -273,29 +285,39 @@ __global__ __launch_bounds__(256) void k_area_fill(QuerySource s, const KpDev* _
                                                    int out_cap, int* __restrict__ err, const uint8_t* __restrict__ desc1,
                                                    const uint8_t* __restrict__ desc2, const long long* __restrict__ frame_base,
                                                    uint32_t* __restrict__ out_pairs) {
-    const int i = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
-    if (i >= s.nq) return;
-    const AreaQuery q = make_query(s, f, i);
-    if (!q.active) return;
+    const int i = (blockIdx.x * 256 + threadIdx.x) / AREA_LPQ, li = threadIdx.x % AREA_LPQ, f = blockIdx.y;
+    AreaQuery q;
+    q.active = false;
+    q.x = q.y = q.r = 0.f;
+    q.min_level = q.max_level = -1;
+    if (i < s.nq) q = make_query(s, f, i);
     const int32_t* st = starts + (long long)f * (s.nq + 1);
-    int o = st[i];
+    const int o = i < s.nq ? st[i] : 0;
+    const KpDev* kf = kp2 + (long long)f * cap2;
+    const int32_t* cs = cell_start + (long long)f * (GRID_CELLS + 1);
+    const int32_t* it = cell_items + (long long)f * cap2;
     if (out_idx) {
-        if (i == 0 && st[s.nq] > out_cap) atomicOr(err, 4);
+        if (i == 0 && li == 0 && st[s.nq] > out_cap) atomicOr(err, 4);
         int32_t* dst = out_idx + (long long)f * out_cap;
-        for_each_in_area(gg, kp2 + (long long)f * cap2, cell_start + (long long)f * (GRID_CELLS + 1),
-                         cell_items + (long long)f * cap2, q, [&](int i2) {
-                             if (o < out_cap) dst[o] = i2;
-                             o++;
-                         });
+        area_group<true>(gg, kf, cs, it, q, li, o, [&](int i2, int pos) {
+            if (pos < out_cap) dst[pos] = i2;
+        });
     } else {
         uint32_t* dst = out_pairs + frame_base[f];
-        const uint4* d1 = (const uint4*)(desc1 + ((long long)f * s.nq + i) * 32);
+        uint4 d1a = make_uint4(0, 0, 0, 0), d1b = d1a;
+        if (q.active) {
+            const uint4* d1 = (const uint4*)(desc1 + ((long long)f * s.nq + i) * 32);
+            d1a = d1[0];
+            d1b = d1[1];
+        }
         const uint8_t* d2f = desc2 + (long long)f * cap2 * 32;
-        for_each_in_area(gg, kp2 + (long long)f * cap2, cell_start + (long long)f * (GRID_CELLS + 1),
-                         cell_items + (long long)f * cap2, q, [&](int i2) {
-                             const int dist = hamming32(d1, (const uint4*)(d2f + (long long)i2 * 32));
-                             dst[o++] = ((uint32_t)dist << 16) | (uint32_t)i2;
-                         });
+        area_group<true>(gg, kf, cs, it, q, li, o, [&](int i2, int pos) {
+            const uint4* t = (const uint4*)(d2f + (long long)i2 * 32);
+            const uint4 a = t[0], b = t[1];
+            const int dist = __popc(a.x ^ d1a.x) + __popc(a.y ^ d1a.y) + __popc(a.z ^ d1a.z) + __popc(a.w ^ d1a.w) +
+                             __popc(b.x ^ d1b.x) + __popc(b.y ^ d1b.y) + __popc(b.z ^ d1b.z) + __popc(b.w ^ d1b.w);
+            dst[pos] = ((uint32_t)dist << 16) | (uint32_t)i2;
+        });
     }
 }
 
@@ -303,20 +325,32 @@ __global__ __launch_bounds__(256) void k_area_fill(QuerySource s, const KpDev* _
 // Resolution: one wave per frame pair.
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
-// the two smallest of the wave's keys (keys are distinct or KEY_NONE)
-__device__ __forceinline__ void wave_two_smallest(unsigned long long k1, unsigned long long k2, unsigned long long& o1,
-                                                  unsigned long long& o2) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long p1 = __shfl_xor(k1, o), p2 = __shfl_xor(k2, o);
-        // merge (k1 <= k2) with (p1 <= p2)
-        const unsigned long long lo = min(k1, p1), hi = max(k1, p1);
-        k2 = min(hi, min(k2, p2));
-        k1 = lo;
-    }
-    o1 = k1;
-    o2 = k2;
+// The two smallest of the wave's 32-bit keys (distinct or KEY32_NONE), by an inclusive scan with DPP
+// row shifts and broadcasts whose combining step keeps the two smallest of two disjoint sets; lane
+// 63 ends up with the result, which is broadcast.
+#define KEY32_NONE 0xffffffffu
+__device__ __forceinline__ void two_smallest_step(uint32_t& k1, uint32_t& k2, uint32_t p1, uint32_t p2) {
+    const uint32_t lo = min(k1, p1), hi = max(k1, p1);
+    k2 = min(hi, min(k2, p2));
+    k1 = lo;
 }
+#define TS_STEP(ctrl, rowmask)                                                                            \
+    {                                                                                                     \
+        const uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp((int)KEY32_NONE, (int)k1, ctrl, rowmask, 0xf, false); \
+        const uint32_t p2 = (uint32_t)__builtin_amdgcn_update_dpp((int)KEY32_NONE, (int)k2, ctrl, rowmask, 0xf, false); \
+        two_smallest_step(k1, k2, p1, p2);                                                                \
+    }
+__device__ __forceinline__ void wave_two_smallest32(uint32_t k1, uint32_t k2, uint32_t& o1, uint32_t& o2) {
+    TS_STEP(0x111, 0xf)  // row_shr:1
+    TS_STEP(0x112, 0xf)  // row_shr:2
+    TS_STEP(0x114, 0xf)  // row_shr:4
+    TS_STEP(0x118, 0xf)  // row_shr:8
+    TS_STEP(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+    TS_STEP(0x143, 0xc)  // row_bcast:31 into rows 2 and 3
+    o1 = (uint32_t)__builtin_amdgcn_readlane((int)k1, 63);
+    o2 = (uint32_t)__builtin_amdgcn_readlane((int)k2, 63);
+}
+#undef TS_STEP
 
 // bin of a match (src/ORBmatcher.cc:493-498, :679-684)
 __device__ __forceinline__ int rot_bin(float a1, float a2) {
@@ -419,7 +453,8 @@ __global__ __launch_bounds__(64) void k_resolve(const KpDev* __restrict__ kp1, c
                 const int i1 = c0 + j;
                 const int s = __shfl(my_s, j), e = __shfl(my_e, j);
                 if (s >= e) continue;
-                unsigned long long k1 = KEY_NONE, k2 = KEY_NONE;
+                // key: distance above, position in the list below (lists hold at most 8192 entries)
+                uint32_t k1 = KEY32_NONE, k2 = KEY32_NONE;
                 for (int b = s; b < e; b += 64) {
                     const int p = b + lane;
                     if (p < e) {
@@ -429,18 +464,19 @@ __global__ __launch_bounds__(64) void k_resolve(const KpDev* __restrict__ kp1, c
                         if (MODE == MODE_SEARCH_INIT) skip = (uint32_t)matchedDist[i2] <= dist;  // :648
                         else skip = m21[i2] != NONE16;                                            // :469
                         if (!skip) {
-                            const unsigned long long key =
-                                ((unsigned long long)dist << 32) | ((unsigned long long)(uint32_t)(p - s) << 16) | i2;
+                            const uint32_t key = (dist << 13) | (uint32_t)(p - s);
                             k2 = min(max(k1, key), k2);
                             k1 = min(k1, key);
                         }
                     }
                 }
-                unsigned long long b1, b2;
-                wave_two_smallest(k1, k2, b1, b2);
-                if (b1 == KEY_NONE) continue;
-                const int bestDist = (int)(b1 >> 32), bestIdx2 = (int)(b1 & 0xffffu);
-                const float fBest2 = b2 == KEY_NONE ? (float)INT_MAX : (float)(int)(b2 >> 32);
+                uint32_t b1, b2;
+                wave_two_smallest32(k1, k2, b1, b2);
+                if (b1 == KEY32_NONE) continue;
+                const int bestDist = (int)(b1 >> 13);
+                const int bpos = s + (int)(b1 & 0x1fffu);
+                const int bestIdx2 = (int)((buffered ? cbuf[bpos - S] : fp[bpos]) & 0xffffu);
+                const float fBest2 = b2 == KEY32_NONE ? (float)INT_MAX : (float)(int)(b2 >> 13);
                 bool accept;
                 if (MODE == MODE_SEARCH_INIT)
                     accept = bestDist <= TH_LOW && (float)bestDist < __fmul_rn(fBest2, ratio);  // :663-665
@@ -587,7 +623,7 @@ int run_matcher(orbhip_matcher* m, int mode, const OrbKeypoint* d_kp1, const uin
     const size_t off_pairs = off_base + align256(sizeof(long long) * (size_t)batch);
     if ((rc = ensure_work(m, off_pairs))) return rc;
     HIPCHK(hipEventRecord(m->ev0, m->stream));
-    dim3 qgrid((cap + 255) / 256, batch);
+    dim3 qgrid((cap * AREA_LPQ + 255) / 256, batch);
     {
         int32_t* starts = (int32_t*)m->d_work;
         int32_t* totals = (int32_t*)((char*)m->d_work + off_tot);
@@ -688,7 +724,7 @@ int orbhip_features_in_area_device(orbhip_matcher* m, const OrbKeypoint* d_kp, c
     s.min_level = s.max_level = -1;
     s.nq = nq;
     const GridGeom gg = make_geom(bounds);
-    dim3 qgrid((std::max(nq, 1) + 255) / 256, batch);
+    dim3 qgrid((std::max(nq, 1) * AREA_LPQ + 255) / 256, batch);
     if (nq)
         hipLaunchKernelGGL(k_area_count, qgrid, dim3(256), 0, m->stream, s, (const KpDev*)d_kp, d_cell_start, d_cell_items, cap,
                            gg, d_out_start);
