@@ -582,6 +582,12 @@ int orbref_extract(orbref_extractor* e, const uint8_t* img, int rows, int cols, 
                     kc.clear();
                     fast9_16(cell, (int)hY, (int)hX, ps, 7, true, kc);
                 }
+                // A cell that is not in the last row/column examines cellH x cellW pixels even when that
+                // carries it past maxBorder (ceil() of the cell size times the cell count can exceed the
+                // bordered extent).  A corner found there makes IC_Angle and the descriptor read rows or
+                // columns outside the image: undefined in the reference, reported here as an error.
+                for (size_t k = 0; k < kc.size(); k++)
+                    if ((int)iniX + kc[k].x >= maxBorderX || (int)iniY + kc[k].y >= maxBorderY) return -2;
                 if (e->scoreType == 0) harris_responses(cell, ps, kc, 7, HARRIS_K);
                 const int nKeys = kc.size();
                 nTotal[i][j] = nKeys;

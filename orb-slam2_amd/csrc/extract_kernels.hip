@@ -473,7 +473,9 @@ __global__ __launch_bounds__(256) void k_quota(const GeomDev* __restrict__ g, co
     const int nfc = L.nfeaturesCell;
     int d = 0, closed = 0;
     for (int c = tid; c < nCells; c += 256) {
-        const bool skipped = lc[c].cw <= 0 || lc[c].ch <= 0;
+        // a visited cell with nothing to examine closes here with zero keys; only a cell the
+        // reference never visits stays open for the loop below
+        const bool skipped = lc[c].skipped != 0;
         const int nKeys = tot[c];
         ltot[c] = nKeys;
         if (skipped) {

@@ -205,12 +205,19 @@ int build_geometry(orbhip_extractor* e, int rows, int cols, GeomDev& g, std::vec
                 const int hY = (i == L.rows - 1) ? maxBY + 3 - c.ini_y : L.cellH + 6;
                 if (hX <= 0 || hY <= 0) {
                     c.cw = c.ch = 0;
+                    c.skipped = 1;
                 } else {
                     // a cell image reaching past the level image makes cv::Mat::colRange throw
                     if (c.ini_x + hX > L.w || c.ini_y + hY > L.h)
                         return orb_fail(ORBHIP_EGEOM, "level %d: cell grid does not fit the %dx%d level", l, L.w, L.h);
-                    if (c.cw < 0) c.cw = 0;  // 0 < hX <= 6: an image with no examined pixel
+                    if (c.cw < 0) c.cw = 0;  // 0 < hX <= 6: a visited cell whose image has no examined pixel
                     if (c.ch < 0) c.ch = 0;
+                    // ceil() cell sizes can carry a cell that is not in the last row/column past the
+                    // border; a corner found there has its orientation patch outside the image, which
+                    // the reference reads without a check
+                    if (c.cw > 0 && c.ch > 0 && (c.x0 + c.cw > maxBX || c.y0 + c.ch > maxBY))
+                        return orb_fail(ORBHIP_EGEOM, "level %d: cell (%d,%d) reaches past the %d-px border of the %dx%d level", l,
+                                        i, j, ORB_EDGE, L.w, L.h);
                 }
                 c.cand_off = cand_off;
                 c.cand_cap = ((std::max(c.cw, 0) + 1) / 2) * ((std::max(c.ch, 0) + 1) / 2);

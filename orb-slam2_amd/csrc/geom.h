@@ -48,11 +48,11 @@ struct GeomDev {
 struct CellDesc {
     int level;
     int index;            // i * levelCols + j
-    int x0, y0, cw, ch;   // cw <= 0 or ch <= 0: the reference skips the cell (:570,:594)
+    int x0, y0, cw, ch;   // examined pixels; cw <= 0 or ch <= 0: no pixel can be a corner
     int ini_x, ini_y;     // iniXCol[j], iniYRow[i]: cell-image origin = x0 - 3, y0 - 3
     long long cand_off;   // offset (keys) of the cell's candidate list in a frame's arena
     int cand_cap;
-    int pad_;
+    int skipped;          // the reference never visits the cell (:570, :594): hX <= 0 or hY <= 0
 };
 
 #ifdef __HIPCC__

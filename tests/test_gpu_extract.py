@@ -212,3 +212,48 @@ def test_harris_batch_and_mode_switch(orb, orbref, synth):
     rkp, rdesc = orbref.RefExtractor(nf, 1.2, 8, 1, 20)(imgs[0])
     dkp, ddesc = devf(imgs[0])
     _assert_same(rkp, rdesc, dkp, ddesc)
+
+
+# (width, height, nfeatures, nlevels, scaleFactor, fastTh, scoreType, frame_idx, flattened) — extreme aspect
+# ratios, one-level pyramids, scale 2.0, cells wider than the LDS-resident FAST kernel takes, a last column
+# whose cell image is 1..6 px wide (visited by the reference, nothing examined: it closes in the first quota
+# pass with zero keys, unlike a column the reference skips)
+ODD_GEOMETRY_CASES = [
+    (113, 624, 232, 3, 1.2, 24, 0, 9807, False),
+    (962, 156, 369, 3, 1.1, 29, 0, 3856, False),
+    (306, 781, 225, 3, 1.1, 31, 1, 7332, False),
+    (369, 723, 2131, 2, 2.0, 11, 1, 3906, False),
+    (216, 614, 356, 6, 1.1, 5, 1, 1951, True),
+    (817, 290, 2530, 8, 1.2, 29, 0, 756, True),
+    (948, 198, 653, 2, 1.2, 5, 1, 9394, True),
+    (867, 584, 2602, 1, 2.0, 42, 1, 7515, False),
+    (380, 140, 2327, 7, 1.2, 11, 0, 3751, False),
+]
+
+
+@pytest.mark.parametrize("case", ODD_GEOMETRY_CASES)
+def test_odd_geometries(orb, orbref, synth, case):
+    w, h, nf, nl, sf, th, st, fi, flat = case
+    img = synth.synth_image(w, h, fi)
+    if flat:
+        img = (img // 8 * 8).astype(np.uint8)
+    dev = orb.ORBextractor(nf, sf, nl, st, th, device=0, max_width=w, max_height=h)
+    ref = orbref.RefExtractor(nf, sf, nl, st, th)
+    rkp, rdesc = ref(img)
+    dkp, ddesc = dev(img)
+    for l in range(nl):
+        assert np.array_equal(ref.level_candidates(l)[0], dev.tap_cells(3, 0, l)), "level %d candidate counts" % l
+        assert np.array_equal(ref.level_retain(l), dev.tap_cells(4, 0, l)), "level %d nToRetain" % l
+    _assert_same(rkp, rdesc, dkp, ddesc)
+    assert len(rkp) > 0
+
+
+def test_cells_past_the_border_are_rejected(orb, orbref, synth):
+    """ceil() cell sizes times the cell count can carry a cell that is not in the last row past maxBorderY
+    (src/ORBextractor.cc:541-545, :564); a corner found there has its 31x31 patch outside the image, which the
+    reference reads unchecked.  The device refuses the geometry; the oracle reports the first such corner."""
+    with pytest.raises(orb.OrbhipError) as ei:
+        orb.ORBextractor(858, 1.3, 1, 1, 43, device=0, max_width=807, max_height=139)(synth.synth_image(807, 139, 7533))
+    assert ei.value.code == -5 and "border" in str(ei.value)
+    with pytest.raises(RuntimeError):
+        orbref.RefExtractor(858, 1.3, 1, 1, 43)(synth.synth_image(807, 139, 7533))
