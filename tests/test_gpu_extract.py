@@ -116,6 +116,23 @@ def test_batch_matches_single(orb, orbref, synth):
         _assert_same(rkp, rdesc, out[f][0], out[f][1])
 
 
+@pytest.mark.parametrize("score", [1, 0])
+def test_large_batch_frame_groups(orb, orbref, synth, score):
+    """One chunk of 19 frames: two full groups of eight frames (whose workgroups the kernels hand to the
+    eight dies one frame each) and a tail of three, every frame checked against the oracle."""
+    w, h, nf, nb = 376, 240, 600, 19
+    dev = orb.ORBextractor(nf, 1.2, 6, score, 20, device=0, max_width=w, max_height=h, max_batch=nb)
+    ref = orbref.RefExtractor(nf, 1.2, 6, score, 20)
+    imgs = synth.synth_batch(w, h, nb, first_idx=40)
+    imgs[5] = 90                               # a blank frame inside a group
+    imgs[17] = (imgs[17] // 8 * 8)             # a flat one in the tail: threshold-7 fallback
+    out = dev.extract_batch(imgs)
+    assert len(out) == nb
+    for f in range(nb):
+        rkp, rdesc = ref(imgs[f])
+        _assert_same(rkp, rdesc, out[f][0], out[f][1])
+
+
 def test_strided_input_and_reuse(orb, orbref, synth):
     """A view with a row stride larger than its width, then a different size on the same handle."""
     dev, ref = _make(orb, orbref, 640, 480, 1000, 8, 20)
