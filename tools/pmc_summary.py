@@ -34,7 +34,7 @@ def main():
     fetch, nf = per_kernel(sys.argv[1], "FETCH_SIZE")
     write, nw = per_kernel(sys.argv[2], "WRITE_SIZE")
     out = {"unit": "bytes per launch", "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, "
-           "ORBHIP_STREAMS=1, python3 bench.py --steps 1 --warmup 0 --no-extra --cpu-sample 1",
+           "ORBHIP_STREAMS=1, " + (sys.argv[4] if len(sys.argv) > 4 else "python3 bench.py --steps 2 --warmup 1 --no-extra --cpu-sample 0"),
            "kernels": {}}
     for k in sorted(fetch):
         fr = fetch[k] / nf[k]
