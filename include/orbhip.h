@@ -222,6 +222,48 @@ int orbhip_window_search_device(orbhip_matcher* m, const OrbKeypoint* d_kp1, con
                                 int window_size, int min_level, int max_level, float nnratio, int check_orientation,
                                 int32_t* d_matches21, int32_t* d_nmatches);
 
+/* One projected map point of the projection matchers: where it falls in the target frame, the
+ * radius and level arguments of the GetFeaturesInArea call the reference makes for it, and the angle
+ * of the keypoint it was observed at (rotation histogram).  valid = 0 stands for every `continue` the
+ * reference takes before that call (no map point, bad, already found, outside the image, ...). */
+typedef struct OrbProbe {
+    float u, v, r;
+    int32_t min_level, max_level;
+    float angle;
+    int32_t valid;
+    int32_t reserved;
+} OrbProbe;
+#define ORBHIP_MAX_PROBES 32768
+/* Acceptance rules of the five ORBmatcher::SearchByProjection overloads */
+#define ORBHIP_PROJ_LOCAL_MAP 0 /* (Frame&, vector<MapPoint*>&, th)  src/ORBmatcher.cc:52-128 */
+#define ORBHIP_PROJ_RATIO 1     /* (Frame&, Frame&, windowSize, ...)  :530-605 */
+#define ORBHIP_PROJ_BEST 2      /* (Frame&, const Frame&, th) :1518-1631; (Frame&, KeyFrame*, ...) :1633-1757;
+                                   (KeyFrame*, Scw, ...) :297-418 — best distance <= th_dist */
+/* Search and assignment loops of ORBmatcher::SearchByProjection for `batch` independent target
+ * frames.  Frame f receives d_nprobes[f] probes d_probes[f*probe_cap ...] with descriptors
+ * d_probe_desc[(f*probe_cap + i)*32 ...], processed in index order as the reference walks its map
+ * points: candidates from GetFeaturesInArea(u, v, r, min_level, max_level) on the frame's grid,
+ * features that already hold a map point skipped — d_taken[f*cap + i2] != 0 on entry (may be NULL)
+ * or assigned by an earlier probe — Hamming distances, acceptance by `rule`, and for
+ * check_orientation != 0 the rotation histogram / three-maxima filter over the new matches.
+ * Output d_match_of_feature (batch*cap): the probe assigned to each feature by this call or -1;
+ * d_nmatches (batch).  probe_cap <= ORBHIP_MAX_PROBES.  Blocking (sizes a workspace from a device
+ * count). */
+int orbhip_search_by_projection_device(orbhip_matcher* m, const OrbProbe* d_probes, const uint8_t* d_probe_desc,
+                                       const int32_t* d_nprobes, int probe_cap, const OrbKeypoint* d_kp2,
+                                       const uint8_t* d_desc2, const int32_t* d_n2, const int32_t* d_cell_start2,
+                                       const int32_t* d_cell_items2, int batch, int cap, OrbFrameBounds bounds,
+                                       const uint8_t* d_taken, int rule, float nnratio, int th_dist, int check_orientation,
+                                       int32_t* d_match_of_feature, int32_t* d_nmatches);
+
+/* Host-pointer form for ONE target frame (copy in, build the frame's grid, match, copy out; blocking):
+ * what a forwarding ORBmatcher::SearchByProjection calls after it has projected its map points with
+ * the reference's own pose arithmetic. */
+int orbhip_search_by_projection(orbhip_matcher* m, const OrbProbe* probes, const uint8_t* probe_desc, int nprobes,
+                                const OrbKeypoint* kp2, const uint8_t* desc2, int n2, OrbFrameBounds bounds,
+                                const uint8_t* taken, int rule, float nnratio, int th_dist, int check_orientation,
+                                int32_t* match_of_feature, int32_t* nmatches);
+
 /* Host-pointer forms of the two matchers for ONE frame pair (copy in, build F2's grid, match, copy
  * out; blocking) — what a forwarding ORBmatcher::SearchForInitialization / WindowSearch calls with
  * the contents of F1.mvKeysUn / mDescriptors and F2's. */

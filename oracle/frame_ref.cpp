@@ -8,6 +8,9 @@
 //   GetFeaturesInArea     src/Frame.cc:201-266
 //   WindowSearch          src/ORBmatcher.cc:420-527
 //   SearchForInitialization  src/ORBmatcher.cc:609-724
+// of the five projection matchers (pose arithmetic included, see the notes above them):
+//   SearchByProjection    src/ORBmatcher.cc:52-128, :297-418, :530-605, :1518-1631, :1633-1757
+//   KeyFrame::GetFeaturesInArea / IsInImage  src/KeyFrame.cc:638-683
 // and of the descriptor choice of a map point:
 //   MapPoint::ComputeDistinctiveDescriptors  src/MapPoint.cc:191-256
 // Arithmetic follows the reference expression by expression in fp32 (this file is compiled with
@@ -300,6 +303,449 @@ int orbref_distinctive_descriptor(const uint8_t* desc, int N, int32_t* best_medi
     }
     if (best_median) *best_median = BestMedian;
     return BestIdx;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// The five ORBmatcher::SearchByProjection overloads.  Map points, poses and cameras arrive as plain
+// arrays; a `skip` flag per map point stands for the pointer tests the reference makes before it
+// projects (NULL, isBad(), membership in an already-found set).  Every function also returns the
+// probe it built per map point (projection, radius, level range, angle, valid) so that a test can
+// hand the same probes to the device search.
+//
+// cv::Mat expressions are restated under these assumptions about OpenCV 2.4 (no OpenCV in this image
+// to confirm them — part of why this file is PARITY UNPINNED):
+//   A*x + t   (3x3 * 3x1 + 3x1, CV_32F)  one cv::gemm call through its small-matrix path: every row
+//             is t0 = a0*x0 + a1*x1 + a2*x2 in float, left to right, then (float)(t0*1.0 + t*1.0)
+//             with the scale factors as doubles;
+//   -A.t()*t  cv::gemm with GEMM_1_T and alpha = -1 through the general path: double accumulation
+//             over k = 0,1,2, times alpha, one rounding to float;
+//   cv::norm  double accumulation of squares, sqrt in double;   Mat::dot  double accumulation;
+//   M / s     M.convertTo(.., 1./s): elementwise float multiply by (float)(1.0/s).
+namespace {
+
+struct ProbeRec {  // same layout as the device probe record
+    float u, v, r;
+    int32_t min_level, max_level;
+    float angle;
+    int32_t valid;
+    int32_t reserved;
+};
+
+void clear_probe(ProbeRec* p) {
+    if (p) memset(p, 0, sizeof(*p));
+}
+
+// Rcw (rows of the 4x4 row-major Tcw) * x + tcw
+void rigid(const float* T, const float* x, float out[3]) {
+    for (int i = 0; i < 3; i++) {
+        const float* a = T + 4 * i;
+        float t0 = a[0] * x[0] + a[1] * x[1] + a[2] * x[2];
+        out[i] = (float)(t0 * 1.0 + a[3] * 1.0);
+    }
+}
+
+// Ow = -Rcw.t()*tcw
+void centre(const float* R /*9, row-major*/, const float* t, float Ow[3]) {
+    for (int i = 0; i < 3; i++) {
+        double s0 = 0;
+        for (int k = 0; k < 3; k++) s0 += (double)R[3 * k + i] * (double)t[k];
+        Ow[i] = (float)(s0 * -1.0);
+    }
+}
+
+double norm3(const float* v) {
+    double s0 = 0;
+    for (int i = 0; i < 3; i++) s0 += (double)v[i] * v[i];
+    return std::sqrt(s0);
+}
+
+double dot3(const float* a, const float* b) {
+    double r = 0;
+    for (int i = 0; i < 3; i++) r += (double)a[i] * b[i];
+    return r;
+}
+
+}  // namespace
+
+// SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th), src/ORBmatcher.cc:52-128.
+// taken[idx] != 0: F.mvpMapPoints[idx] is set on entry.  match_of_feature[idx] = iMP assigned by this call, else -1.
+int orbref_sbp_local_map(const void* kp, const uint8_t* desc, int n, const int32_t bounds[4], const float* mvScaleFactors,
+                         const uint8_t* taken, int nmp, const uint8_t* mbTrackInView, const uint8_t* bad,
+                         const int32_t* mnTrackScaleLevel, const float* mTrackViewCos, const float* mTrackProjX,
+                         const float* mTrackProjY, const uint8_t* mp_desc, float th, float mfNNratio,
+                         int32_t* match_of_feature, void* probes_out) {
+    FrameRef F(kp, desc, n, bounds);
+    ProbeRec* pr = (ProbeRec*)probes_out;
+    std::vector<char> has(n);
+    for (int i = 0; i < n; i++) {
+        has[i] = taken && taken[i];
+        match_of_feature[i] = -1;
+    }
+    int nmatches = 0;
+    const bool bFactor = th != 1.0;
+    for (size_t iMP = 0; iMP < (size_t)nmp; iMP++) {
+        clear_probe(pr ? pr + iMP : nullptr);
+        if (!mbTrackInView[iMP]) continue;
+        if (bad[iMP]) continue;
+        const int& nPredictedLevel = mnTrackScaleLevel[iMP];
+        float r = mTrackViewCos[iMP] > 0.998 ? 2.5 : 4.0;  // RadiusByViewingCos, :130-136
+        if (bFactor) r *= th;
+        const float rr = r * mvScaleFactors[nPredictedLevel];
+        if (pr) {
+            ProbeRec& q = pr[iMP];
+            q.u = mTrackProjX[iMP];
+            q.v = mTrackProjY[iMP];
+            q.r = rr;
+            q.min_level = nPredictedLevel - 1;
+            q.max_level = nPredictedLevel;
+            q.valid = 1;
+        }
+        std::vector<size_t> vNearIndices = F.GetFeaturesInArea(mTrackProjX[iMP], mTrackProjY[iMP], rr, nPredictedLevel - 1, nPredictedLevel);
+        if (vNearIndices.empty()) continue;
+        const uint8_t* MPdescriptor = mp_desc + iMP * 32;
+        int bestDist = INT_MAX;
+        int bestLevel = -1;
+        int bestDist2 = INT_MAX;
+        int bestLevel2 = -1;
+        int bestIdx = -1;
+        for (size_t idx : vNearIndices) {
+            if (has[idx]) continue;
+            const int dist = orbref_hamming(MPdescriptor, desc + idx * 32);
+            if (dist < bestDist) {
+                bestDist2 = bestDist;
+                bestDist = dist;
+                bestLevel2 = bestLevel;
+                bestLevel = F.kp[idx].octave;
+                bestIdx = (int)idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = F.kp[idx].octave;
+                bestDist2 = dist;
+            }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == bestLevel2 && bestDist > mfNNratio * bestDist2) continue;
+            has[bestIdx] = 1;
+            match_of_feature[bestIdx] = (int32_t)iMP;
+            nmatches++;
+        }
+    }
+    return nmatches;
+}
+
+// SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, vector<MapPoint*> &vpMatched, int th),
+// src/ORBmatcher.cc:297-418.  skip[i]: isBad() or in spAlreadyFound.  matched[idx] != 0: vpMatched[idx] set on entry.
+int orbref_sbp_sim3(const void* kp, const uint8_t* desc, int n, const int32_t bounds[4], float fx, float fy, float cx, float cy,
+                    const float* vfScaleFactors, int nlevels, const float* Scw /*4x4 row-major*/, const uint8_t* matched,
+                    int npoints, const uint8_t* skip, const float* pos, const float* normal, const float* minDistArr,
+                    const float* maxDistArr, const uint8_t* mp_desc, int th, int32_t* match_of_feature, void* probes_out) {
+    FrameRef KF(kp, desc, n, bounds);
+    ProbeRec* pr = (ProbeRec*)probes_out;
+    const int nMaxLevel = nlevels - 1;
+    // Decompose Scw
+    float sR[9], Rcw[9], tcw[3], Ow[3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) sR[3 * i + j] = Scw[4 * i + j];
+    const float scw = std::sqrt(dot3(sR, sR));
+    const float inv = (float)(1. / scw);
+    for (int i = 0; i < 9; i++) Rcw[i] = sR[i] * inv;
+    for (int i = 0; i < 3; i++) tcw[i] = Scw[4 * i + 3] * inv;
+    centre(Rcw, tcw, Ow);
+    float T[16] = {Rcw[0], Rcw[1], Rcw[2], tcw[0], Rcw[3], Rcw[4], Rcw[5], tcw[1], Rcw[6], Rcw[7], Rcw[8], tcw[2], 0, 0, 0, 1};
+    std::vector<char> has(n);
+    for (int i = 0; i < n; i++) {
+        has[i] = matched && matched[i];
+        match_of_feature[i] = -1;
+    }
+    int nmatches = 0;
+    for (int iMP = 0, iendMP = npoints; iMP < iendMP; iMP++) {
+        clear_probe(pr ? pr + iMP : nullptr);
+        if (skip[iMP]) continue;
+        const float* p3Dw = pos + 3 * iMP;
+        float p3Dc[3];
+        rigid(T, p3Dw, p3Dc);
+        if (p3Dc[2] < 0.0) continue;
+        const float invz = 1 / p3Dc[2];
+        const float x = p3Dc[0] * invz;
+        const float y = p3Dc[1] * invz;
+        const float u = fx * x + cx;
+        const float v = fy * y + cy;
+        if (!(u >= KF.mnMinX && u < KF.mnMaxX && v >= KF.mnMinY && v < KF.mnMaxY)) continue;  // KeyFrame::IsInImage
+        const float maxDistance = maxDistArr[iMP];
+        const float minDistance = minDistArr[iMP];
+        float PO[3] = {p3Dw[0] - Ow[0], p3Dw[1] - Ow[1], p3Dw[2] - Ow[2]};
+        const float dist3 = norm3(PO);
+        if (dist3 < minDistance || dist3 > maxDistance) continue;
+        if (dot3(PO, normal + 3 * iMP) < 0.5 * dist3) continue;
+        const float ratio = dist3 / minDistance;
+        const float* it = std::lower_bound(vfScaleFactors, vfScaleFactors + nlevels, ratio);
+        const int nPredictedLevel = std::min(static_cast<int>(it - vfScaleFactors), nMaxLevel);
+        const float radius = th * vfScaleFactors[nPredictedLevel];
+        if (pr) {
+            ProbeRec& q = pr[iMP];
+            q.u = u;
+            q.v = v;
+            q.r = radius;
+            q.min_level = nPredictedLevel - 1;
+            q.max_level = nPredictedLevel;
+            q.valid = 1;
+        }
+        std::vector<size_t> vIndices = KF.GetFeaturesInArea(u, v, radius, -1, -1);  // KeyFrame::GetFeaturesInArea, src/KeyFrame.cc:638-678
+        if (vIndices.empty()) continue;
+        const uint8_t* dMP = mp_desc + (size_t)iMP * 32;
+        int bestDist = INT_MAX;
+        int bestIdx = -1;
+        for (size_t idx : vIndices) {
+            if (has[idx]) continue;
+            const int kpLevel = KF.kp[idx].octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            const int dist = orbref_hamming(dMP, desc + idx * 32);
+            if (dist < bestDist) {
+                bestDist = dist;
+                bestIdx = (int)idx;
+            }
+        }
+        if (bestDist <= TH_LOW) {
+            has[bestIdx] = 1;
+            match_of_feature[bestIdx] = iMP;
+            nmatches++;
+        }
+    }
+    return nmatches;
+}
+
+// SearchByProjection(Frame &F1, Frame &F2, int windowSize, vector<MapPoint*> &vpMapPointMatches2), src/ORBmatcher.cc:530-605.
+// skip1[i1]: F1.mvpMapPoints[i1] is NULL, bad, or already among F2's map points.  taken2: F2.mvpMapPoints set on entry.
+int orbref_sbp_frames(const void* kp1, const uint8_t* desc1, int n1, const uint8_t* skip1, const float* pos1,
+                      const float* Tc2w /*4x4 row-major*/, float fx, float fy, float cx, float cy, const void* kp2,
+                      const uint8_t* desc2, int n2, const int32_t bounds[4], const uint8_t* taken2, int windowSize,
+                      float mfNNratio, int32_t* match_of_feature2, void* probes_out) {
+    FrameRef F1(kp1, desc1, n1, bounds), F2(kp2, desc2, n2, bounds);
+    ProbeRec* pr = (ProbeRec*)probes_out;
+    std::vector<char> has(n2);
+    for (int i = 0; i < n2; i++) {
+        has[i] = taken2 && taken2[i];
+        match_of_feature2[i] = -1;
+    }
+    int nmatches = 0;
+    for (size_t i1 = 0, iend1 = n1; i1 < iend1; i1++) {
+        clear_probe(pr ? pr + i1 : nullptr);
+        if (skip1[i1]) continue;
+        int level1 = F1.kp[i1].octave;
+        float x3Dc2[3];
+        rigid(Tc2w, pos1 + 3 * i1, x3Dc2);
+        const float xc2 = x3Dc2[0];
+        const float yc2 = x3Dc2[1];
+        const float invzc2 = 1.0 / x3Dc2[2];
+        float u2 = fx * xc2 * invzc2 + cx;
+        float v2 = fy * yc2 * invzc2 + cy;
+        if (pr) {
+            ProbeRec& q = pr[i1];
+            q.u = u2;
+            q.v = v2;
+            q.r = windowSize;
+            q.min_level = q.max_level = level1;
+            q.valid = 1;
+        }
+        std::vector<size_t> vIndices2 = F2.GetFeaturesInArea(u2, v2, windowSize, level1, level1);
+        if (vIndices2.empty()) continue;
+        const uint8_t* d1 = desc1 + i1 * 32;
+        int bestDist = INT_MAX;
+        int bestDist2 = INT_MAX;
+        int bestIdx2 = -1;
+        for (size_t i2 : vIndices2) {
+            if (has[i2]) continue;
+            int dist = orbref_hamming(d1, desc2 + i2 * 32);
+            if (dist < bestDist) {
+                bestDist2 = bestDist;
+                bestDist = dist;
+                bestIdx2 = (int)i2;
+            } else if (dist < bestDist2) {
+                bestDist2 = dist;
+            }
+        }
+        if (static_cast<float>(bestDist) <= static_cast<float>(bestDist2) * mfNNratio && bestDist <= TH_HIGH) {
+            has[bestIdx2] = 1;
+            match_of_feature2[bestIdx2] = (int32_t)i1;
+            nmatches++;
+        }
+    }
+    return nmatches;
+}
+
+namespace {
+
+// Shared tail of the two tracking overloads: rotation histogram filter (:1608-1628, :1735-1754)
+int rotation_filter(std::vector<int>* rotHist, int32_t* match_of_feature, int nmatches) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+        if (i != ind1 && i != ind2 && i != ind3) {
+            for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+                match_of_feature[rotHist[i][j]] = -1;
+                nmatches--;
+            }
+        }
+    }
+    return nmatches;
+}
+
+}  // namespace
+
+// SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, float th), src/ORBmatcher.cc:1518-1631.
+// skip_last[i]: LastFrame.mvpMapPoints[i] is NULL or LastFrame.mvbOutlier[i].
+int orbref_sbp_last_frame(const void* kp_cur, const uint8_t* desc_cur, int n_cur, const int32_t bounds[4], const uint8_t* taken_cur,
+                          float fx, float fy, float cx, float cy, const float* Tcw /*4x4 row-major*/,
+                          const float* mvScaleFactors, const void* kp_last, const uint8_t* desc_last, int n_last,
+                          const uint8_t* skip_last, const float* pos_last, float th, int mbCheckOrientation,
+                          int32_t* match_of_feature, void* probes_out) {
+    FrameRef CurrentFrame(kp_cur, desc_cur, n_cur, bounds);
+    const Kp* last = (const Kp*)kp_last;
+    ProbeRec* pr = (ProbeRec*)probes_out;
+    std::vector<char> has(n_cur);
+    for (int i = 0; i < n_cur; i++) {
+        has[i] = taken_cur && taken_cur[i];
+        match_of_feature[i] = -1;
+    }
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (size_t i = 0, iend = n_last; i < iend; i++) {
+        clear_probe(pr ? pr + i : nullptr);
+        if (skip_last[i]) continue;
+        float x3Dc[3];
+        rigid(Tcw, pos_last + 3 * i, x3Dc);
+        const float xc = x3Dc[0];
+        const float yc = x3Dc[1];
+        const float invzc = 1.0 / x3Dc[2];
+        float u = fx * xc * invzc + cx;
+        float v = fy * yc * invzc + cy;
+        if (u < CurrentFrame.mnMinX || u > CurrentFrame.mnMaxX) continue;
+        if (v < CurrentFrame.mnMinY || v > CurrentFrame.mnMaxY) continue;
+        int nPredictedOctave = last[i].octave;
+        float radius = th * mvScaleFactors[nPredictedOctave];
+        if (pr) {
+            ProbeRec& q = pr[i];
+            q.u = u;
+            q.v = v;
+            q.r = radius;
+            q.min_level = nPredictedOctave - 1;
+            q.max_level = nPredictedOctave + 1;
+            q.angle = last[i].angle;
+            q.valid = 1;
+        }
+        std::vector<size_t> vIndices2 = CurrentFrame.GetFeaturesInArea(u, v, radius, nPredictedOctave - 1, nPredictedOctave + 1);
+        if (vIndices2.empty()) continue;
+        const uint8_t* dMP = desc_last + i * 32;
+        int bestDist = INT_MAX;
+        int bestIdx2 = -1;
+        for (size_t i2 : vIndices2) {
+            if (has[i2]) continue;
+            int dist = orbref_hamming(dMP, desc_cur + i2 * 32);
+            if (dist < bestDist) {
+                bestDist = dist;
+                bestIdx2 = (int)i2;
+            }
+        }
+        if (bestDist <= TH_HIGH) {
+            has[bestIdx2] = 1;
+            match_of_feature[bestIdx2] = (int32_t)i;
+            nmatches++;
+            if (mbCheckOrientation) {
+                float rot = last[i].angle - CurrentFrame.kp[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (mbCheckOrientation) nmatches = rotation_filter(rotHist, match_of_feature, nmatches);
+    return nmatches;
+}
+
+// SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, float th, int ORBdist),
+// src/ORBmatcher.cc:1633-1757.  skip_kf[i]: pKF's map point i is NULL, bad or in sAlreadyFound.  kf_angle[i] =
+// pKF->GetKeyPointUn(i).angle; mp_desc = pMP->GetDescriptor().
+int orbref_sbp_keyframe(const void* kp_cur, const uint8_t* desc_cur, int n_cur, const int32_t bounds[4], const uint8_t* taken_cur,
+                        float fx, float fy, float cx, float cy, const float* Tcw /*4x4 row-major*/, const float* mvScaleFactors,
+                        int mnScaleLevels, int n_kf, const uint8_t* skip_kf, const float* pos, const float* minDistArr,
+                        const uint8_t* mp_desc, const float* kf_angle, float th, int ORBdist, int mbCheckOrientation,
+                        int32_t* match_of_feature, void* probes_out) {
+    FrameRef CurrentFrame(kp_cur, desc_cur, n_cur, bounds);
+    ProbeRec* pr = (ProbeRec*)probes_out;
+    std::vector<char> has(n_cur);
+    for (int i = 0; i < n_cur; i++) {
+        has[i] = taken_cur && taken_cur[i];
+        match_of_feature[i] = -1;
+    }
+    int nmatches = 0;
+    float Rcw[9], tcw[3], Ow[3];
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) Rcw[3 * i + j] = Tcw[4 * i + j];
+        tcw[i] = Tcw[4 * i + 3];
+    }
+    centre(Rcw, tcw, Ow);
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (size_t i = 0, iend = n_kf; i < iend; i++) {
+        clear_probe(pr ? pr + i : nullptr);
+        if (skip_kf[i]) continue;
+        const float* x3Dw = pos + 3 * i;
+        float x3Dc[3];
+        rigid(Tcw, x3Dw, x3Dc);
+        const float xc = x3Dc[0];
+        const float yc = x3Dc[1];
+        const float invzc = 1.0 / x3Dc[2];
+        float u = fx * xc * invzc + cx;
+        float v = fy * yc * invzc + cy;
+        if (u < CurrentFrame.mnMinX || u > CurrentFrame.mnMaxX) continue;
+        if (v < CurrentFrame.mnMinY || v > CurrentFrame.mnMaxY) continue;
+        float minDistance = minDistArr[i];
+        float PO[3] = {x3Dw[0] - Ow[0], x3Dw[1] - Ow[1], x3Dw[2] - Ow[2]};
+        float dist3D = norm3(PO);
+        float ratio = dist3D / minDistance;
+        const float* it = std::lower_bound(mvScaleFactors, mvScaleFactors + mnScaleLevels, ratio);
+        const int nPredictedLevel = std::min(static_cast<int>(it - mvScaleFactors), mnScaleLevels - 1);
+        float radius = th * mvScaleFactors[nPredictedLevel];
+        if (pr) {
+            ProbeRec& q = pr[i];
+            q.u = u;
+            q.v = v;
+            q.r = radius;
+            q.min_level = nPredictedLevel - 1;
+            q.max_level = nPredictedLevel + 1;
+            q.angle = kf_angle[i];
+            q.valid = 1;
+        }
+        std::vector<size_t> vIndices2 = CurrentFrame.GetFeaturesInArea(u, v, radius, nPredictedLevel - 1, nPredictedLevel + 1);
+        if (vIndices2.empty()) continue;
+        const uint8_t* dMP = mp_desc + i * 32;
+        int bestDist = INT_MAX;
+        int bestIdx2 = -1;
+        for (size_t i2 : vIndices2) {
+            if (has[i2]) continue;
+            int dist = orbref_hamming(dMP, desc_cur + i2 * 32);
+            if (dist < bestDist) {
+                bestDist = dist;
+                bestIdx2 = (int)i2;
+            }
+        }
+        if (bestDist <= ORBdist) {
+            has[bestIdx2] = 1;
+            match_of_feature[bestIdx2] = (int32_t)i;
+            nmatches++;
+            if (mbCheckOrientation) {
+                float rot = kf_angle[i] - CurrentFrame.kp[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (mbCheckOrientation) nmatches = rotation_filter(rotHist, match_of_feature, nmatches);
+    return nmatches;
 }
 
 }  // extern "C"

@@ -87,6 +87,12 @@ def lib():
         L.orbref_bow_score_l1.argtypes = [vp, vp, i32, vp, vp, i32]
         L.orbref_distinctive_descriptor.argtypes = [vp, i32, vp]
         L.orbref_window_search.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, f32, i32, vp]
+        L.orbref_sbp_local_map.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, f32, f32, vp, vp]
+        L.orbref_sbp_sim3.argtypes = [vp, vp, i32, vp, f32, f32, f32, f32, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp]
+        L.orbref_sbp_frames.argtypes = [vp, vp, i32, vp, vp, vp, f32, f32, f32, f32, vp, vp, i32, vp, vp, i32, f32, vp, vp]
+        L.orbref_sbp_last_frame.argtypes = [vp, vp, i32, vp, vp, f32, f32, f32, f32, vp, vp, vp, vp, i32, vp, vp, f32, i32, vp, vp]
+        L.orbref_sbp_keyframe.argtypes = [vp, vp, i32, vp, vp, f32, f32, f32, f32, vp, vp, i32, i32, vp, vp, vp, vp, vp, f32,
+                                          i32, i32, vp, vp]
         _lib = L
     return _lib
 
@@ -246,6 +252,96 @@ def window_search(kp1, desc1, valid1, kp2, desc2, bounds, window_size, min_level
     n = lib().orbref_window_search(_p(kp1), _p(desc1), len(kp1), _p(valid1), _p(kp2), _p(desc2), len(kp2), _p(b),
                                    window_size, min_level, max_level, nnratio, int(check_orientation), _p(m21))
     return n, m21[:len(kp2)].copy()
+
+
+PROBE_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("r", "<f4"), ("min_level", "<i4"), ("max_level", "<i4"),
+                        ("angle", "<f4"), ("valid", "<i4"), ("reserved", "<i4")])
+
+
+def _frame(kp, desc):
+    return (np.ascontiguousarray(kp, dtype=KP_DTYPE), np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 32))
+
+
+def _u8(a, n):
+    return np.zeros(max(n, 1), np.uint8) if a is None else np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def sbp_local_map(kp, desc, bounds, scale_factors, taken, track_in_view, bad, level, view_cos, proj_x, proj_y, mp_desc,
+                  th, nnratio):
+    """SearchByProjection(Frame&, vector<MapPoint*>&, th): (nmatches, match_of_feature, probes)."""
+    kp, desc = _frame(kp, desc)
+    nmp = len(level)
+    out = np.zeros(max(len(kp), 1), np.int32)
+    probes = np.zeros(max(nmp, 1), PROBE_DTYPE)
+    sf, b = _f32(scale_factors), _bounds(bounds)
+    args = [_u8(track_in_view, nmp), _u8(bad, nmp), np.ascontiguousarray(level, dtype=np.int32), _f32(view_cos),
+            _f32(proj_x), _f32(proj_y), np.ascontiguousarray(mp_desc, dtype=np.uint8)]
+    tk = _u8(taken, len(kp))
+    n = lib().orbref_sbp_local_map(_p(kp), _p(desc), len(kp), _p(b), _p(sf), _p(tk), nmp, *[_p(a) for a in args], th, nnratio,
+                                   _p(out), _p(probes))
+    return n, out[:len(kp)].copy(), probes[:nmp].copy()
+
+
+def sbp_sim3(kp, desc, bounds, K, scale_factors, Scw, matched, skip, pos, normal, min_dist, max_dist, mp_desc, th):
+    """SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th): (nmatches, match_of_feature, probes)."""
+    kp, desc = _frame(kp, desc)
+    npts = len(skip)
+    out = np.zeros(max(len(kp), 1), np.int32)
+    probes = np.zeros(max(npts, 1), PROBE_DTYPE)
+    sf, b, S = _f32(scale_factors), _bounds(bounds), _f32(Scw).reshape(16)
+    mt = _u8(matched, len(kp))
+    args = [_u8(skip, npts), _f32(pos), _f32(normal), _f32(min_dist), _f32(max_dist), np.ascontiguousarray(mp_desc, dtype=np.uint8)]
+    n = lib().orbref_sbp_sim3(_p(kp), _p(desc), len(kp), _p(b), K[0], K[1], K[2], K[3], _p(sf), len(sf), _p(S), _p(mt), npts,
+                              *[_p(a) for a in args], int(th), _p(out), _p(probes))
+    return n, out[:len(kp)].copy(), probes[:npts].copy()
+
+
+def sbp_frames(kp1, desc1, skip1, pos1, Tc2w, K, kp2, desc2, bounds, taken2, window_size, nnratio):
+    """SearchByProjection(Frame &F1, Frame &F2, windowSize, vpMapPointMatches2): (nmatches, match_of_feature2, probes)."""
+    kp1, desc1 = _frame(kp1, desc1)
+    kp2, desc2 = _frame(kp2, desc2)
+    out = np.zeros(max(len(kp2), 1), np.int32)
+    probes = np.zeros(max(len(kp1), 1), PROBE_DTYPE)
+    b, T = _bounds(bounds), _f32(Tc2w).reshape(16)
+    sk, ps, tk = _u8(skip1, len(kp1)), _f32(pos1), _u8(taken2, len(kp2))
+    n = lib().orbref_sbp_frames(_p(kp1), _p(desc1), len(kp1), _p(sk), _p(ps), _p(T), K[0], K[1], K[2], K[3], _p(kp2), _p(desc2),
+                                len(kp2), _p(b), _p(tk), int(window_size), nnratio, _p(out), _p(probes))
+    return n, out[:len(kp2)].copy(), probes[:len(kp1)].copy()
+
+
+def sbp_last_frame(kp_cur, desc_cur, bounds, taken_cur, K, Tcw, scale_factors, kp_last, desc_last, skip_last, pos_last, th,
+                   check_orientation):
+    """SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th): (nmatches, match_of_feature, probes)."""
+    kp_cur, desc_cur = _frame(kp_cur, desc_cur)
+    kp_last, desc_last = _frame(kp_last, desc_last)
+    out = np.zeros(max(len(kp_cur), 1), np.int32)
+    probes = np.zeros(max(len(kp_last), 1), PROBE_DTYPE)
+    b, T, sf = _bounds(bounds), _f32(Tcw).reshape(16), _f32(scale_factors)
+    tk, sk, ps = _u8(taken_cur, len(kp_cur)), _u8(skip_last, len(kp_last)), _f32(pos_last)
+    n = lib().orbref_sbp_last_frame(_p(kp_cur), _p(desc_cur), len(kp_cur), _p(b), _p(tk), K[0], K[1], K[2], K[3], _p(T), _p(sf),
+                                    _p(kp_last), _p(desc_last), len(kp_last), _p(sk), _p(ps), th, int(check_orientation),
+                                    _p(out), _p(probes))
+    return n, out[:len(kp_cur)].copy(), probes[:len(kp_last)].copy()
+
+
+def sbp_keyframe(kp_cur, desc_cur, bounds, taken_cur, K, Tcw, scale_factors, skip_kf, pos, min_dist, mp_desc, kf_angle, th,
+                 orb_dist, check_orientation):
+    """SearchByProjection(Frame &CurrentFrame, KeyFrame*, sAlreadyFound, th, ORBdist): (nmatches, match_of_feature, probes)."""
+    kp_cur, desc_cur = _frame(kp_cur, desc_cur)
+    nkf = len(skip_kf)
+    out = np.zeros(max(len(kp_cur), 1), np.int32)
+    probes = np.zeros(max(nkf, 1), PROBE_DTYPE)
+    b, T, sf = _bounds(bounds), _f32(Tcw).reshape(16), _f32(scale_factors)
+    tk = _u8(taken_cur, len(kp_cur))
+    args = [_u8(skip_kf, nkf), _f32(pos), _f32(min_dist), np.ascontiguousarray(mp_desc, dtype=np.uint8), _f32(kf_angle)]
+    n = lib().orbref_sbp_keyframe(_p(kp_cur), _p(desc_cur), len(kp_cur), _p(b), _p(tk), K[0], K[1], K[2], K[3], _p(T), _p(sf),
+                                  len(sf), nkf, *[_p(a) for a in args], th, int(orb_dist), int(check_orientation), _p(out),
+                                  _p(probes))
+    return n, out[:len(kp_cur)].copy(), probes[:nkf].copy()
 
 
 def distinctive_descriptor(desc):

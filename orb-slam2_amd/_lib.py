@@ -105,6 +105,9 @@ def lib():
     L.orbhip_distinctive_descriptors_device.argtypes = [vp, vp, vp, i32, vp, vp]
     L.orbhip_window_search_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, OrbFrameBounds,
                                               i32, i32, i32, f32, i32, vp, vp]
+    L.orbhip_search_by_projection_device.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, OrbFrameBounds,
+                                                     vp, i32, f32, i32, i32, vp, vp]
+    L.orbhip_search_by_projection.argtypes = [vp, vp, vp, i32, vp, vp, i32, OrbFrameBounds, vp, i32, f32, i32, i32, vp, vp]
     L.orbhip_device_count.argtypes = []
     L.orbhip_version.restype = C.c_char_p
     L.orbhip_last_error.restype = C.c_char_p

@@ -181,10 +181,11 @@ __device__ __forceinline__ int area_group(const GridGeom& gg, const KpDev* __res
 }
 
 // How the queries of a frame are defined.
-enum { MODE_EXPLICIT = 0, MODE_SEARCH_INIT = 1, MODE_WINDOW = 2 };
+enum { MODE_EXPLICIT = 0, MODE_SEARCH_INIT = 1, MODE_WINDOW = 2, MODE_PROBE = 3 };
 struct QuerySource {
     int mode;
     const OrbAreaQuery* queries;  // MODE_EXPLICIT: nq per frame
+    const OrbProbe* probes;       // MODE_PROBE: nq per frame, n1[f] of them in use
     const KpDev* kp1;             // the matchers: keypoints of F1 (cap per frame)
     const int32_t* n1;
     const float* prev;            // MODE_SEARCH_INIT: vbPrevMatched (cap * 2 floats per frame)
@@ -210,6 +211,19 @@ __device__ __forceinline__ AreaQuery make_query(const QuerySource& s, int f, int
         return q;
     }
     if (i >= s.n1[f]) return q;
+    if (s.mode == MODE_PROBE) {
+        const OrbProbe& e = s.probes[(long long)f * s.nq + i];
+        // a projection that is not a number reaches GetFeaturesInArea in the reference, where the
+        // float -> int conversions are undefined: such a probe is dropped here
+        if (!e.valid || !(fabsf(e.u) <= 3.0e38f) || !(fabsf(e.v) <= 3.0e38f) || !(fabsf(e.r) <= 3.0e38f)) return q;
+        q.x = e.u;
+        q.y = e.v;
+        q.r = e.r;
+        q.min_level = e.min_level;
+        q.max_level = e.max_level;
+        q.active = true;
+        return q;
+    }
     const KpDev& k = s.kp1[(long long)f * s.nq + i];
     const int level1 = k.octave;
     q.r = s.r;
@@ -591,45 +605,30 @@ int ensure_work(orbhip_matcher* m, size_t bytes) {
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-// Shared body of the two matchers.
-int run_matcher(orbhip_matcher* m, int mode, const OrbKeypoint* d_kp1, const uint8_t* d_desc1, const int32_t* d_n1,
-                const uint8_t* d_valid1, const OrbKeypoint* d_kp2, const uint8_t* d_desc2, const int32_t* d_n2,
-                const int32_t* d_cell_start2, const int32_t* d_cell_items2, int batch, int cap, OrbFrameBounds bounds,
-                float* d_prev, int window_size, int min_level, int max_level, float ratio, int check_ori,
-                int32_t* d_matches, int32_t* d_nmatches) {
-    int rc = check_frames(m, batch, cap, bounds);
-    if (rc) return rc;
-    if (batch == 0) return ORBHIP_OK;
-    if (!d_kp1 || !d_desc1 || !d_n1 || !d_kp2 || !d_desc2 || !d_n2 || !d_cell_start2 || !d_cell_items2 || !d_matches ||
-        !d_nmatches || (mode == MODE_SEARCH_INIT && !d_prev) || (mode == MODE_WINDOW && !d_valid1))
-        return orb_fail(ORBHIP_EINVAL, "null buffer");
-    HIPCHK(hipSetDevice(m->device));
-    (void)hipGetLastError();
-    const GridGeom gg = make_geom(bounds);
-    QuerySource s;
-    s.mode = mode;
-    s.queries = nullptr;
-    s.kp1 = (const KpDev*)d_kp1;
-    s.n1 = d_n1;
-    s.prev = d_prev;
-    s.valid1 = d_valid1;
-    s.r = (float)window_size;  // int windowSize binds to "const float &r"
-    s.min_level = min_level;
-    s.max_level = max_level;
-    s.nq = cap;
-    // workspace: starts [batch*(cap+1)] | totals [batch] | frame_base [batch] (int64) | pairs
-    const size_t off_tot = align256(sizeof(int32_t) * (size_t)batch * (cap + 1));
+// Candidate stage shared by all matchers: count pass, per-frame scan, fill pass.  On return the
+// workspace holds starts [batch*(nq+1)], the per-frame bases and the (distance << 16 | i2) lists.
+struct Candidates {
+    int32_t* starts;
+    long long* d_base;
+    uint32_t* pairs;
+};
+
+int build_candidates(orbhip_matcher* m, const QuerySource& s, const uint8_t* d_desc1, const KpDev* d_kp2, const uint8_t* d_desc2,
+                     const int32_t* d_cell_start2, const int32_t* d_cell_items2, int batch, int cap2, const GridGeom& gg,
+                     Candidates& out) {
+    int rc;
+    const int nq = s.nq;
+    // workspace: starts [batch*(nq+1)] | totals [batch] | frame_base [batch] (int64) | pairs
+    const size_t off_tot = align256(sizeof(int32_t) * (size_t)batch * (nq + 1));
     const size_t off_base = off_tot + align256(sizeof(int32_t) * (size_t)batch);
     const size_t off_pairs = off_base + align256(sizeof(long long) * (size_t)batch);
     if ((rc = ensure_work(m, off_pairs))) return rc;
-    HIPCHK(hipEventRecord(m->ev0, m->stream));
-    dim3 qgrid((cap * AREA_LPQ + 255) / 256, batch);
+    dim3 qgrid((nq * AREA_LPQ + 255) / 256, batch);
     {
         int32_t* starts = (int32_t*)m->d_work;
         int32_t* totals = (int32_t*)((char*)m->d_work + off_tot);
-        hipLaunchKernelGGL(k_area_count, qgrid, dim3(256), 0, m->stream, s, (const KpDev*)d_kp2, d_cell_start2, d_cell_items2,
-                           cap, gg, starts);
-        hipLaunchKernelGGL(k_scan_counts, dim3(batch), dim3(256), 0, m->stream, starts, cap, totals);
+        hipLaunchKernelGGL(k_area_count, qgrid, dim3(256), 0, m->stream, s, d_kp2, d_cell_start2, d_cell_items2, cap2, gg, starts);
+        hipLaunchKernelGGL(k_scan_counts, dim3(batch), dim3(256), 0, m->stream, starts, nq, totals);
     }
     std::vector<int32_t> totals(batch);
     HIPCHK(hipMemcpyAsync(totals.data(), (char*)m->d_work + off_tot, sizeof(int32_t) * batch, hipMemcpyDeviceToHost,
@@ -656,29 +655,189 @@ int run_matcher(orbhip_matcher* m, int mode, const OrbKeypoint* d_kp1, const uin
         hipFree(old);
         if (ce != hipSuccess) return orb_fail(ORBHIP_EHIP, "workspace copy failed: %s", hipGetErrorString(ce));
     }
-    int32_t* starts = (int32_t*)m->d_work;
-    long long* d_base = (long long*)((char*)m->d_work + off_base);
-    uint32_t* pairs = (uint32_t*)((char*)m->d_work + off_pairs);
-    HIPCHK(hipMemcpyAsync(d_base, base.data(), sizeof(long long) * batch, hipMemcpyHostToDevice, m->stream));
+    out.starts = (int32_t*)m->d_work;
+    out.d_base = (long long*)((char*)m->d_work + off_base);
+    out.pairs = (uint32_t*)((char*)m->d_work + off_pairs);
+    HIPCHK(hipMemcpyAsync(out.d_base, base.data(), sizeof(long long) * batch, hipMemcpyHostToDevice, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));  // `base` is a stack-lifetime host buffer
-    hipLaunchKernelGGL(k_area_fill, qgrid, dim3(256), 0, m->stream, s, (const KpDev*)d_kp2, d_cell_start2, d_cell_items2, cap,
-                       gg, starts, (int32_t*)nullptr, 0, m->d_err, d_desc1, d_desc2, d_base, pairs);
+    hipLaunchKernelGGL(k_area_fill, qgrid, dim3(256), 0, m->stream, s, d_kp2, d_cell_start2, d_cell_items2, cap2, gg, out.starts,
+                       (int32_t*)nullptr, 0, m->d_err, d_desc1, d_desc2, out.d_base, out.pairs);
+    return ORBHIP_OK;
+}
+
+// Shared body of SearchForInitialization and WindowSearch.
+int run_matcher(orbhip_matcher* m, int mode, const OrbKeypoint* d_kp1, const uint8_t* d_desc1, const int32_t* d_n1,
+                const uint8_t* d_valid1, const OrbKeypoint* d_kp2, const uint8_t* d_desc2, const int32_t* d_n2,
+                const int32_t* d_cell_start2, const int32_t* d_cell_items2, int batch, int cap, OrbFrameBounds bounds,
+                float* d_prev, int window_size, int min_level, int max_level, float ratio, int check_ori,
+                int32_t* d_matches, int32_t* d_nmatches) {
+    int rc = check_frames(m, batch, cap, bounds);
+    if (rc) return rc;
+    if (batch == 0) return ORBHIP_OK;
+    if (!d_kp1 || !d_desc1 || !d_n1 || !d_kp2 || !d_desc2 || !d_n2 || !d_cell_start2 || !d_cell_items2 || !d_matches ||
+        !d_nmatches || (mode == MODE_SEARCH_INIT && !d_prev) || (mode == MODE_WINDOW && !d_valid1))
+        return orb_fail(ORBHIP_EINVAL, "null buffer");
+    HIPCHK(hipSetDevice(m->device));
+    (void)hipGetLastError();
+    const GridGeom gg = make_geom(bounds);
+    QuerySource s;
+    s.mode = mode;
+    s.queries = nullptr;
+    s.probes = nullptr;
+    s.kp1 = (const KpDev*)d_kp1;
+    s.n1 = d_n1;
+    s.prev = d_prev;
+    s.valid1 = d_valid1;
+    s.r = (float)window_size;  // int windowSize binds to "const float &r"
+    s.min_level = min_level;
+    s.max_level = max_level;
+    s.nq = cap;
+    HIPCHK(hipEventRecord(m->ev0, m->stream));
+    Candidates c;
+    if ((rc = build_candidates(m, s, d_desc1, (const KpDev*)d_kp2, d_desc2, d_cell_start2, d_cell_items2, batch, cap, gg, c)))
+        return rc;
     const size_t lds = sizeof(uint16_t) * 4 * (size_t)cap + sizeof(uint32_t) * RB_CAP;
     if (mode == MODE_SEARCH_INIT) {
         HIPCHK(hipFuncSetAttribute((const void*)k_resolve<MODE_SEARCH_INIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_resolve<MODE_SEARCH_INIT>, dim3(batch), dim3(64), lds, m->stream, (const KpDev*)d_kp1, d_n1,
-                           (const KpDev*)d_kp2, d_n2, cap, starts, d_base, pairs, ratio, check_ori, d_prev, d_matches,
+                           (const KpDev*)d_kp2, d_n2, cap, c.starts, c.d_base, c.pairs, ratio, check_ori, d_prev, d_matches,
                            d_nmatches);
     } else {
         HIPCHK(hipFuncSetAttribute((const void*)k_resolve<MODE_WINDOW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_resolve<MODE_WINDOW>, dim3(batch), dim3(64), lds, m->stream, (const KpDev*)d_kp1, d_n1,
-                           (const KpDev*)d_kp2, d_n2, cap, starts, d_base, pairs, ratio, check_ori, d_prev, d_matches,
+                           (const KpDev*)d_kp2, d_n2, cap, c.starts, c.d_base, c.pairs, ratio, check_ori, d_prev, d_matches,
                            d_nmatches);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(m->ev1, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
     return ORBHIP_OK;
+}
+
+// Resolution of the projection matchers: one wave per target frame walks the probes (projected
+// map points) in order.  A feature of the frame that already holds a map point, on entry or from
+// an earlier probe, is skipped (src/ORBmatcher.cc:94, :389, :578, :1573, :1698).
+//   RULE_LOCAL_MAP  :101-124   best and second with their levels; accepted if best <= TH_HIGH unless
+//                               both are on one level and best > ratio * second
+//   RULE_RATIO      :585-600   (float)best <= (float)second * ratio && best <= TH_HIGH
+//   RULE_BEST       :1580-1590, :1705-1715, :401-413   best <= th_dist
+// LDS: owner of every feature (uint16: free, taken on entry, or probe index), the run buffer, the
+// histogram.
+enum { RULE_LOCAL_MAP = 0, RULE_RATIO = 1, RULE_BEST = 2 };
+#define TAKEN16 0xfffeu
+template <int RULE>
+__global__ __launch_bounds__(64) void k_resolve_probe(const OrbProbe* __restrict__ probes, const int32_t* __restrict__ np_arr,
+                                                      int pcap, const KpDev* __restrict__ kp2, const int32_t* __restrict__ n2_arr,
+                                                      int cap2, const int32_t* __restrict__ starts,
+                                                      const long long* __restrict__ frame_base, const uint32_t* __restrict__ pairs,
+                                                      const uint8_t* __restrict__ taken, float ratio, int th_dist, int check_ori,
+                                                      int32_t* __restrict__ matches_out, int32_t* __restrict__ nmatches_out) {
+    extern __shared__ uint16_t lds16[];
+    __shared__ int hist[HISTO_LENGTH + 2];
+    __shared__ int nm_sh;
+    const int f = blockIdx.x, lane = threadIdx.x;
+    const int np = min(max(np_arr[f], 0), pcap), n2 = min(max(n2_arr[f], 0), cap2);
+    uint16_t* owner = lds16;
+    const int cap2e = (cap2 + 1) & ~1;
+    uint32_t* cbuf = (uint32_t*)(lds16 + cap2e);
+    for (int i = lane; i < cap2; i += 64) owner[i] = (taken && i < n2 && taken[(long long)f * cap2 + i]) ? TAKEN16 : NONE16;
+    if (lane < HISTO_LENGTH + 2) hist[lane] = 0;
+    wave_fence();
+    const int32_t* st = starts + (long long)f * (pcap + 1);
+    const uint32_t* fp = pairs + frame_base[f];
+    const KpDev* k2f = kp2 + (long long)f * cap2;
+    const OrbProbe* pf = probes + (long long)f * pcap;
+    int nmatches = 0;
+    for (int c0 = 0; c0 < np; c0 += 64) {
+        const int ci = min(c0 + lane, np);
+        const int my_s = st[ci], my_e = st[min(ci + 1, pcap)];
+        const int chunk = min(64, np - c0);
+        int j0 = 0;
+        while (j0 < chunk) {
+            const int S = __shfl(my_s, j0);
+            const unsigned long long fit = __ballot(lane >= j0 && lane < chunk && my_e - S <= RB_CAP);
+            const int q = __popcll(fit);
+            const bool buffered = q > 0;
+            const int jn = buffered ? j0 + q : j0 + 1;
+            if (buffered) {
+                const int E = __shfl(my_e, jn - 1);
+                for (int p = S + lane; p < E; p += 64) cbuf[p - S] = fp[p];
+                wave_fence();
+            }
+            for (int j = j0; j < jn; j++) {
+                const int ip = c0 + j;
+                const int s = __shfl(my_s, j), e = __shfl(my_e, j);
+                if (s >= e) continue;
+                uint32_t k1 = KEY32_NONE, k2 = KEY32_NONE;
+                for (int b = s; b < e; b += 64) {
+                    const int p = b + lane;
+                    if (p < e) {
+                        const uint32_t pr = buffered ? cbuf[p - S] : fp[p];
+                        const uint32_t i2 = pr & 0xffffu, dist = pr >> 16;
+                        if (owner[i2] == NONE16) {
+                            const uint32_t key = (dist << 13) | (uint32_t)(p - s);
+                            k2 = min(max(k1, key), k2);
+                            k1 = min(k1, key);
+                        }
+                    }
+                }
+                uint32_t b1, b2;
+                wave_two_smallest32(k1, k2, b1, b2);
+                if (b1 == KEY32_NONE) continue;
+                const int bestDist = (int)(b1 >> 13);
+                const int bpos = s + (int)(b1 & 0x1fffu);
+                const int bestIdx = (int)((buffered ? cbuf[bpos - S] : fp[bpos]) & 0xffffu);
+                bool accept;
+                if (RULE == RULE_LOCAL_MAP) {
+                    accept = bestDist <= TH_HIGH;
+                    if (accept && b2 != KEY32_NONE) {
+                        const int spos = s + (int)(b2 & 0x1fffu);
+                        const int secondIdx = (int)((buffered ? cbuf[spos - S] : fp[spos]) & 0xffffu);
+                        const int bestDist2 = (int)(b2 >> 13);
+                        if (k2f[bestIdx].octave == k2f[secondIdx].octave && (float)bestDist > __fmul_rn(ratio, (float)bestDist2))
+                            accept = false;
+                    }
+                } else if (RULE == RULE_RATIO) {
+                    const float fBest2 = b2 == KEY32_NONE ? (float)INT_MAX : (float)(int)(b2 >> 13);
+                    accept = (float)bestDist <= __fmul_rn(fBest2, ratio) && bestDist <= TH_HIGH;
+                } else {
+                    accept = bestDist <= th_dist;
+                }
+                if (accept) {
+                    wave_fence();
+                    if (lane == 0) owner[bestIdx] = (uint16_t)ip;
+                    nmatches++;
+                    wave_fence();
+                }
+            }
+            wave_fence();  // the buffer is reused by the next run
+            j0 = jn;
+        }
+    }
+    wave_fence();
+    if (lane == 0) nm_sh = 0;
+    wave_fence();
+    if (check_ori) {  // :1592-1602 and :1608-1628
+        for (int i2 = lane; i2 < n2; i2 += 64)
+            if (owner[i2] < TAKEN16) atomicAdd(&hist[rot_bin(pf[owner[i2]].angle, k2f[i2].angle)], 1);
+        wave_fence();
+        const uint32_t keep = three_maxima_mask(hist);
+        int removed = 0;
+        for (int i2 = lane; i2 < n2; i2 += 64)
+            if (owner[i2] < TAKEN16 && !((keep >> rot_bin(pf[owner[i2]].angle, k2f[i2].angle)) & 1u)) {
+                owner[i2] = NONE16;
+                removed++;
+            }
+        if (removed) atomicAdd(&nm_sh, removed);
+        wave_fence();
+    }
+    nmatches -= nm_sh;
+    if (lane == 0) nmatches_out[f] = nmatches;
+    int32_t* mo = matches_out + (long long)f * cap2;
+    for (int i2 = lane; i2 < cap2; i2 += 64) {
+        const uint32_t v = i2 < n2 ? owner[i2] : NONE16;
+        mo[i2] = v < TAKEN16 ? (int32_t)v : -1;
+    }
 }
 
 }  // namespace
@@ -716,6 +875,7 @@ int orbhip_features_in_area_device(orbhip_matcher* m, const OrbKeypoint* d_kp, c
     QuerySource s;
     s.mode = MODE_EXPLICIT;
     s.queries = d_queries;
+    s.probes = nullptr;
     s.kp1 = nullptr;
     s.n1 = nullptr;
     s.prev = nullptr;
@@ -757,6 +917,55 @@ int orbhip_window_search_device(orbhip_matcher* m, const OrbKeypoint* d_kp1, con
     return run_matcher(m, MODE_WINDOW, d_kp1, d_desc1, d_n1, d_valid1, d_kp2, d_desc2, d_n2, d_cell_start2, d_cell_items2,
                        batch, cap, bounds, nullptr, window_size, min_level, max_level, nnratio, check_orientation,
                        d_matches21, d_nmatches);
+}
+
+int orbhip_search_by_projection_device(orbhip_matcher* m, const OrbProbe* d_probes, const uint8_t* d_probe_desc,
+                                       const int32_t* d_nprobes, int probe_cap, const OrbKeypoint* d_kp2,
+                                       const uint8_t* d_desc2, const int32_t* d_n2, const int32_t* d_cell_start2,
+                                       const int32_t* d_cell_items2, int batch, int cap, OrbFrameBounds bounds,
+                                       const uint8_t* d_taken, int rule, float nnratio, int th_dist, int check_orientation,
+                                       int32_t* d_match_of_feature, int32_t* d_nmatches) {
+    int rc = check_frames(m, batch, cap, bounds);
+    if (rc) return rc;
+    if (probe_cap < 1 || probe_cap > ORBHIP_MAX_PROBES)
+        return orb_fail(ORBHIP_ECAP, "probe_cap %d outside 1..%d", probe_cap, ORBHIP_MAX_PROBES);
+    if (rule != ORBHIP_PROJ_LOCAL_MAP && rule != ORBHIP_PROJ_RATIO && rule != ORBHIP_PROJ_BEST)
+        return orb_fail(ORBHIP_EINVAL, "unknown acceptance rule %d", rule);
+    if (batch == 0) return ORBHIP_OK;
+    if (!d_probes || !d_probe_desc || !d_nprobes || !d_kp2 || !d_desc2 || !d_n2 || !d_cell_start2 || !d_cell_items2 ||
+        !d_match_of_feature || !d_nmatches)
+        return orb_fail(ORBHIP_EINVAL, "null buffer");
+    HIPCHK(hipSetDevice(m->device));
+    (void)hipGetLastError();
+    const GridGeom gg = make_geom(bounds);
+    QuerySource s;
+    s.mode = MODE_PROBE;
+    s.queries = nullptr;
+    s.probes = d_probes;
+    s.kp1 = nullptr;
+    s.n1 = d_nprobes;
+    s.prev = nullptr;
+    s.valid1 = nullptr;
+    s.r = 0.f;
+    s.min_level = s.max_level = -1;
+    s.nq = probe_cap;
+    HIPCHK(hipEventRecord(m->ev0, m->stream));
+    Candidates c;
+    if ((rc = build_candidates(m, s, d_probe_desc, (const KpDev*)d_kp2, d_desc2, d_cell_start2, d_cell_items2, batch, cap, gg, c)))
+        return rc;
+    const size_t lds = sizeof(uint16_t) * (size_t)((cap + 1) & ~1) + sizeof(uint32_t) * RB_CAP;
+#define LAUNCH_PROBE(R)                                                                                                   \
+    hipLaunchKernelGGL(k_resolve_probe<R>, dim3(batch), dim3(64), lds, m->stream, d_probes, d_nprobes, probe_cap,          \
+                       (const KpDev*)d_kp2, d_n2, cap, c.starts, c.d_base, c.pairs, d_taken, nnratio, th_dist,              \
+                       check_orientation, d_match_of_feature, d_nmatches)
+    if (rule == ORBHIP_PROJ_LOCAL_MAP) LAUNCH_PROBE(RULE_LOCAL_MAP);
+    else if (rule == ORBHIP_PROJ_RATIO) LAUNCH_PROBE(RULE_RATIO);
+    else LAUNCH_PROBE(RULE_BEST);
+#undef LAUNCH_PROBE
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(m->ev1, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return ORBHIP_OK;
 }
 
 }  // extern "C"
@@ -877,6 +1086,65 @@ int orbhip_window_search(orbhip_matcher* m, const OrbKeypoint* kp1, const uint8_
         return rc;
     if (n2) HIPCHK(hipMemcpy(matches21, ps.matches, sizeof(int32_t) * n2, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(nmatches, ps.nmatches, sizeof(int32_t), hipMemcpyDeviceToHost));
+    return ORBHIP_OK;
+}
+
+int orbhip_search_by_projection(orbhip_matcher* m, const OrbProbe* probes, const uint8_t* probe_desc, int nprobes,
+                                const OrbKeypoint* kp2, const uint8_t* desc2, int n2, OrbFrameBounds bounds,
+                                const uint8_t* taken, int rule, float nnratio, int th_dist, int check_orientation,
+                                int32_t* match_of_feature, int32_t* nmatches) {
+    if (!m) return orb_fail(ORBHIP_EINVAL, "null matcher");
+    if (nprobes < 0 || n2 < 0) return orb_fail(ORBHIP_EINVAL, "negative size");
+    if (!nmatches || (nprobes && (!probes || !probe_desc)) || (n2 && (!kp2 || !desc2 || !match_of_feature)))
+        return orb_fail(ORBHIP_EINVAL, "null buffer");
+    const int cap = std::max(1, n2), pcap = std::max(1, nprobes);
+    int rc = check_frames(m, 1, cap, bounds);
+    if (rc) return rc;
+    if (pcap > ORBHIP_MAX_PROBES) return orb_fail(ORBHIP_ECAP, "%d probes > %d", nprobes, ORBHIP_MAX_PROBES);
+    HIPCHK(hipSetDevice(m->device));
+    // staging: probes | probe descriptors | keypoints | descriptors | taken | n[2] | grid | matches | nmatches
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off += align256(bytes);
+        return o;
+    };
+    const size_t o_pr = take(sizeof(OrbProbe) * pcap), o_pd = take(32 * (size_t)pcap), o_kp = take(sizeof(OrbKeypoint) * cap);
+    const size_t o_d = take(32 * (size_t)cap), o_t = take(cap), o_n = take(sizeof(int32_t) * 2);
+    const size_t o_cs = take(sizeof(int32_t) * (GRID_CELLS + 1)), o_ci = take(sizeof(int32_t) * cap);
+    const size_t o_m = take(sizeof(int32_t) * cap), o_nm = take(sizeof(int32_t));
+    if (off > m->stage_bytes) {
+        if (m->d_stage) hipFree(m->d_stage);
+        m->d_stage = nullptr;
+        m->stage_bytes = 0;
+        if (hipMalloc(&m->d_stage, off) != hipSuccess) return orb_fail(ORBHIP_ENOMEM, "hipMalloc of %zu bytes failed", off);
+        m->stage_bytes = off;
+    }
+    char* b = (char*)m->d_stage;
+    const int32_t n[2] = {nprobes, n2};
+    HIPCHK(hipMemcpyAsync(b + o_n, n, sizeof(n), hipMemcpyHostToDevice, m->stream));
+    if (nprobes) {
+        HIPCHK(hipMemcpyAsync(b + o_pr, probes, sizeof(OrbProbe) * nprobes, hipMemcpyHostToDevice, m->stream));
+        HIPCHK(hipMemcpyAsync(b + o_pd, probe_desc, 32 * (size_t)nprobes, hipMemcpyHostToDevice, m->stream));
+    }
+    if (n2) {
+        HIPCHK(hipMemcpyAsync(b + o_kp, kp2, sizeof(OrbKeypoint) * n2, hipMemcpyHostToDevice, m->stream));
+        HIPCHK(hipMemcpyAsync(b + o_d, desc2, 32 * (size_t)n2, hipMemcpyHostToDevice, m->stream));
+        if (taken) HIPCHK(hipMemcpyAsync(b + o_t, taken, n2, hipMemcpyHostToDevice, m->stream));
+    }
+    HIPCHK(hipStreamSynchronize(m->stream));  // n[] lives on this stack frame
+    if ((rc = orbhip_frame_grid_device(m, (const OrbKeypoint*)(b + o_kp), (const int32_t*)(b + o_n) + 1, 1, cap, bounds,
+                                       (int32_t*)(b + o_cs), (int32_t*)(b + o_ci))))
+        return rc;
+    if ((rc = orbhip_search_by_projection_device(m, (const OrbProbe*)(b + o_pr), (const uint8_t*)(b + o_pd),
+                                                 (const int32_t*)(b + o_n), pcap, (const OrbKeypoint*)(b + o_kp),
+                                                 (const uint8_t*)(b + o_d), (const int32_t*)(b + o_n) + 1,
+                                                 (const int32_t*)(b + o_cs), (const int32_t*)(b + o_ci), 1, cap, bounds,
+                                                 taken ? (const uint8_t*)(b + o_t) : nullptr, rule, nnratio, th_dist,
+                                                 check_orientation, (int32_t*)(b + o_m), (int32_t*)(b + o_nm))))
+        return rc;
+    if (n2) HIPCHK(hipMemcpy(match_of_feature, b + o_m, sizeof(int32_t) * n2, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(nmatches, b + o_nm, sizeof(int32_t), hipMemcpyDeviceToHost));
     return ORBHIP_OK;
 }
 

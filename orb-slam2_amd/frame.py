@@ -15,6 +15,9 @@ FRAME_GRID_COLS = 64  # include/Frame.h:38
 GRID_CELLS = FRAME_GRID_ROWS * FRAME_GRID_COLS
 
 AREA_QUERY_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("r", "<f4"), ("min_level", "<i4"), ("max_level", "<i4")])
+# OrbProbe of include/orbhip.h: one projected map point of the SearchByProjection overloads
+PROBE_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("r", "<f4"), ("min_level", "<i4"), ("max_level", "<i4"),
+                        ("angle", "<f4"), ("valid", "<i4"), ("reserved", "<i4")])
 
 
 class FrameBatch:

@@ -114,6 +114,55 @@ class ORBmatcher:
             int(self.mbCheckOrientation), m21.data_ptr(), nm.data_ptr()))
         return nm, m21
 
+    # acceptance rules of the SearchByProjection overloads (include/orbhip.h)
+    PROJ_LOCAL_MAP, PROJ_RATIO, PROJ_BEST = 0, 1, 2
+
+    def SearchByProjection(self, F, probes, probe_desc, nprobes, rule, taken=None, th_dist=TH_HIGH, check_orientation=None):
+        """Search and assignment loops of the five ORBmatcher::SearchByProjection overloads
+        (src/ORBmatcher.cc:52-128, :297-418, :530-605, :1518-1631, :1633-1757) on a batch of target frames.
+        probes: uint8 CUDA tensor [batch, probe_cap, 32] of PROBE_DTYPE records (one per projected map point,
+        in the order the reference walks them), probe_desc: uint8 [batch, probe_cap, 32], nprobes: int32 [batch],
+        taken: uint8 [batch, cap], non-zero where the frame's feature already holds a map point.
+        Returns (nmatches [batch], match_of_feature [batch, cap]: probe index assigned to the feature or -1)."""
+        import torch
+        assert probes.is_cuda and probes.dtype == torch.uint8 and probes.is_contiguous() and probes.shape[-1] == 32
+        assert probe_desc.is_cuda and probe_desc.dtype == torch.uint8 and probe_desc.is_contiguous()
+        assert probes.shape[0] == F.batch and probe_desc.shape[:2] == probes.shape[:2]
+        assert nprobes.is_cuda and nprobes.dtype == torch.int32
+        if taken is not None:
+            assert taken.is_cuda and taken.dtype == torch.uint8 and taken.is_contiguous() and tuple(taken.shape) == (F.batch, F.cap)
+        dev = F.n.device
+        out = torch.empty((F.batch, F.cap), dtype=torch.int32, device=dev)
+        nm = torch.empty(F.batch, dtype=torch.int32, device=dev)
+        ori = self.mbCheckOrientation if check_orientation is None else check_orientation
+        torch.cuda.synchronize()
+        _lib.check(self._L.orbhip_search_by_projection_device(
+            self._h, probes.data_ptr(), probe_desc.data_ptr(), nprobes.data_ptr(), int(probes.shape[1]), F.kp.data_ptr(),
+            F.desc.data_ptr(), F.n.data_ptr(), F.cell_start.data_ptr(), F.cell_items.data_ptr(), F.batch, F.cap, F.bounds,
+            0 if taken is None else taken.data_ptr(), int(rule), self.mfNNratio, int(th_dist), int(ori), out.data_ptr(),
+            nm.data_ptr()))
+        return nm, out
+
+    def search_by_projection_host(self, probes, probe_desc, kp2, desc2, bounds, rule, taken=None, th_dist=TH_HIGH,
+                                  check_orientation=None):
+        """One target frame from host arrays (what a forwarding ORBmatcher::SearchByProjection does after
+        projecting its map points).  Returns (nmatches, match_of_feature)."""
+        from .extractor import KP_DTYPE
+        from .frame import PROBE_DTYPE
+        probes = np.ascontiguousarray(probes, dtype=PROBE_DTYPE)
+        probe_desc = np.ascontiguousarray(probe_desc, dtype=np.uint8).reshape(-1, 32)
+        kp2 = np.ascontiguousarray(kp2, dtype=KP_DTYPE)
+        desc2 = np.ascontiguousarray(desc2, dtype=np.uint8).reshape(-1, 32)
+        tk = None if taken is None else np.ascontiguousarray(taken, dtype=np.uint8)
+        out = np.full(max(len(kp2), 1), -1, np.int32)
+        nm = C.c_int32(0)
+        ori = self.mbCheckOrientation if check_orientation is None else check_orientation
+        _lib.check(self._L.orbhip_search_by_projection(
+            self._h, _p(probes), _p(probe_desc), len(probes), _p(kp2), _p(desc2), len(kp2),
+            _lib.OrbFrameBounds(*map(int, bounds)), None if tk is None else _p(tk), int(rule), self.mfNNratio, int(th_dist),
+            int(ori), _p(out), C.byref(nm)))
+        return nm.value, out[:len(kp2)].copy()
+
     def search_for_initialization_host(self, kp1, desc1, kp2, desc2, bounds, prev_matched, windowSize=10):
         """One frame pair from host arrays (what a forwarding ORBmatcher::SearchForInitialization does).
         Returns (nmatches, vnMatches12, updated vbPrevMatched)."""

@@ -1,8 +1,8 @@
 // The accelerated primitive of the reference's ORBmatcher, with its signature unchanged:
 //   static int ORBmatcher::DescriptorDistance(const cv::Mat &a, const cv::Mat &b)
 // (include/ORBmatcher.h:46, src/ORBmatcher.cc:1805-1821).  In the reference tree the body of that
-// one function is replaced by the single forwarding line below; the 13 Search*/Fuse methods keep
-// their CPU bodies and call it as before.  Batched dense matching goes through orbhip_knn2*.
+// one function is replaced by the single forwarding line below; Search*/Fuse methods without a forwarding
+// body here keep their CPU bodies and call it as before.  Batched dense matching goes through orbhip_knn2*.
 #ifndef ORBMATCHER_ACCEL_H
 #define ORBMATCHER_ACCEL_H
 #ifdef ORBHIP_SHIM_CV_STUB
@@ -83,6 +83,58 @@ struct ORBmatcherAccel {
             throw std::runtime_error(orbhip_last_error());
         for (int i2 = 0; i2 < n2; i2++)
             if (vnMatches21[i2] >= 0) vpMapPointMatches2[i2] = F1.mvpMapPoints[vnMatches21[i2]];
+        return nmatches;
+    }
+
+    // int SearchByProjection(Frame &F, const std::vector<MapPoint*> &vpMapPoints, const float th = 3)
+    // (include/ORBmatcher.h:54, src/ORBmatcher.cc:52-128): the lines that read the tracking fields of a map
+    // point stay as in the reference and fill one probe each; the search and assignment loops run on the
+    // device.  FrameT additionally needs mvScaleFactors; MapPointT needs mbTrackInView, mnTrackScaleLevel,
+    // mTrackViewCos, mTrackProjX, mTrackProjY and GetDescriptor().
+    static float RadiusByViewingCos(const float& viewCos) {
+        if (viewCos > 0.998)
+            return 2.5;
+        else
+            return 4.0;
+    }
+    template <class FrameT, class MapPointT>
+    int SearchByProjection(FrameT& F, const std::vector<MapPointT*>& vpMapPoints, const float th = 3) {
+        const int n = (int)F.mvKeysUn.size(), nmp = (int)vpMapPoints.size();
+        std::vector<OrbProbe> probes(nmp ? nmp : 1);
+        std::vector<unsigned char> pdesc((size_t)(nmp ? nmp : 1) * 32);
+        const bool bFactor = th != 1.0;
+        for (int iMP = 0; iMP < nmp; iMP++) {
+            OrbProbe& q = probes[iMP];
+            q.u = q.v = q.r = q.angle = 0.f;
+            q.min_level = q.max_level = q.valid = q.reserved = 0;
+            MapPointT* pMP = vpMapPoints[iMP];
+            if (!pMP->mbTrackInView) continue;
+            if (pMP->isBad()) continue;
+            const int& nPredictedLevel = pMP->mnTrackScaleLevel;
+            float r = RadiusByViewingCos(pMP->mTrackViewCos);
+            if (bFactor) r *= th;
+            q.u = pMP->mTrackProjX;
+            q.v = pMP->mTrackProjY;
+            q.r = r * F.mvScaleFactors[nPredictedLevel];
+            q.min_level = nPredictedLevel - 1;
+            q.max_level = nPredictedLevel;
+            q.valid = 1;
+            cv::Mat MPdescriptor = pMP->GetDescriptor();
+            const unsigned char* d = MPdescriptor.template ptr<unsigned char>(0);
+            for (int b = 0; b < 32; b++) pdesc[(size_t)iMP * 32 + b] = d[b];
+        }
+        std::vector<unsigned char> taken(n ? n : 1);
+        for (int i = 0; i < n; i++) taken[i] = F.mvpMapPoints[i] != 0;
+        const std::vector<unsigned char> d2 = packDescriptors(F);
+        const OrbFrameBounds b = {FrameT::mnMinX, FrameT::mnMinY, FrameT::mnMaxX, FrameT::mnMaxY};
+        std::vector<int> owner(n ? n : 1, -1);
+        int nmatches = 0;
+        if (orbhip_search_by_projection(handle, probes.data(), pdesc.data(), nmp, (const OrbKeypoint*)F.mvKeysUn.data(),
+                                        d2.data(), n, b, taken.data(), ORBHIP_PROJ_LOCAL_MAP, mfNNratio, TH_HIGH, 0,
+                                        owner.data(), &nmatches) != ORBHIP_OK)
+            throw std::runtime_error(orbhip_last_error());
+        for (int i = 0; i < n; i++)
+            if (owner[i] >= 0) F.mvpMapPoints[i] = vpMapPoints[owner[i]];
         return nmatches;
     }
 };

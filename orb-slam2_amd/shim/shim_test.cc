@@ -12,13 +12,20 @@
 // Stand-ins with the members of ORB_SLAM::Frame / MapPoint the forwarding matchers touch.
 struct FakeMapPoint {
     bool bad;
-    FakeMapPoint() : bad(false) {}
+    // tracking fields written by Frame::isInFrustum (include/MapPoint.h)
+    bool mbTrackInView;
+    int mnTrackScaleLevel;
+    float mTrackViewCos, mTrackProjX, mTrackProjY;
+    cv::Mat descriptor;
+    FakeMapPoint() : bad(false), mbTrackInView(false), mnTrackScaleLevel(0), mTrackViewCos(1.f), mTrackProjX(0.f), mTrackProjY(0.f) {}
     bool isBad() const { return bad; }
+    cv::Mat GetDescriptor() const { return descriptor; }
 };
 struct FakeFrame {
     std::vector<cv::KeyPoint> mvKeysUn;
     cv::Mat mDescriptors;
     std::vector<FakeMapPoint*> mvpMapPoints;
+    std::vector<float> mvScaleFactors;
     static int mnMinX, mnMinY, mnMaxX, mnMaxY;
 };
 int FakeFrame::mnMinX, FakeFrame::mnMinY, FakeFrame::mnMaxX, FakeFrame::mnMaxY;
@@ -82,6 +89,33 @@ int main(int argc, char** argv) {
     for (int i = 0; i < n2; i++) {
         int has = mp2[i] != 0;
         fwrite(&has, 4, 1, f);
+    }
+    // SearchByProjection(Frame&, vector<MapPoint*>&, th): one map point per keypoint of frame 1, predicted at
+    // that keypoint moved by the known image shift, matched into frame 2
+    std::vector<FakeMapPoint> pts(n);
+    std::vector<FakeMapPoint*> vp(n);
+    for (int i = 0; i < n; i++) {
+        pts[i].bad = i % 13 == 0;
+        pts[i].mbTrackInView = i % 5 != 0;
+        pts[i].mnTrackScaleLevel = keys[i].octave;
+        pts[i].mTrackViewCos = i % 3 == 0 ? 0.9985f : 0.99f;
+        pts[i].mTrackProjX = keys[i].pt.x + 5.f;
+        pts[i].mTrackProjY = keys[i].pt.y + 3.f;
+        pts[i].descriptor = descriptors.row(i);
+        vp[i] = &pts[i];
+    }
+    F2.mvScaleFactors.resize(8);
+    F2.mvScaleFactors[0] = 1.f;
+    for (int l = 1; l < 8; l++) F2.mvScaleFactors[l] = F2.mvScaleFactors[l - 1] * 1.2f;
+    for (int i = 0; i < n2; i++) F2.mvpMapPoints[i] = i % 9 == 0 ? &good : (FakeMapPoint*)0;
+    ORB_SLAM::ORBmatcherAccel matcher8(0.8f, true);
+    int nProj = matcher8.SearchByProjection(F2, vp, 3.f);
+    fwrite(&nProj, 4, 1, f);
+    for (int i = 0; i < n2; i++) {
+        int owner = -1;  // -2: the map point the feature held on entry
+        if (F2.mvpMapPoints[i] == &good) owner = -2;
+        else if (F2.mvpMapPoints[i]) owner = (int)(F2.mvpMapPoints[i] - &pts[0]);
+        fwrite(&owner, 4, 1, f);
     }
     fclose(f);
     return 0;

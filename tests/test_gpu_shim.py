@@ -61,3 +61,19 @@ def test_cpp_shim_matches_oracle(orb, orbref, synth, tmp_path):
     rn, r21 = orbref.window_search(rkp, rdesc, valid, rkp2, rdesc2, bounds, 50, 0, 2**31 - 1, np.float32(0.9), True)
     assert n_win == rn and rn > 20
     assert np.array_equal(has2 != 0, r21 >= 0)
+    o += 4 * n2
+
+    # the forwarding SearchByProjection(Frame&, vector<MapPoint*>&, th) body
+    n_proj = int(np.frombuffer(blob[o:o + 4], np.int32)[0])
+    o += 4
+    owner = np.frombuffer(blob[o:o + 4 * n2], np.int32)
+    scale = np.ones(8, np.float32)
+    for l in range(1, 8):
+        scale[l] = scale[l - 1] * np.float32(1.2)
+    taken = (np.arange(n2) % 9 == 0).astype(np.uint8)
+    rn, rmatch, _ = orbref.sbp_local_map(
+        rkp2, rdesc2, bounds, scale, taken, (idx % 5 != 0).astype(np.uint8), (idx % 13 == 0).astype(np.uint8),
+        rkp["octave"], np.where(idx % 3 == 0, np.float32(0.9985), np.float32(0.99)).astype(np.float32),
+        rkp["x"] + np.float32(5), rkp["y"] + np.float32(3), rdesc, 3.0, np.float32(0.8))
+    assert n_proj == rn and rn > 50
+    assert np.array_equal(owner, np.where(taken != 0, -2, rmatch))

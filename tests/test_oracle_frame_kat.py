@@ -185,3 +185,123 @@ def test_search_by_bow_by_hand(orbref):
     fvb = (np.array([5, 7, 9], np.int32), np.array([0, 1, 2, 3], np.int32), np.array([1, 0, 2], np.int32))
     n, m12 = orbref.search_by_bow_kf_kf(kp, d1, ones, fv, kp, d2, ones, fvb, 0.7, False)
     assert n == 2 and list(m12) == [1, -1, 2]  # node 5 of keyframe 2 now holds only feature 1
+
+
+def test_projection_last_frame_by_hand(orbref):
+    """SearchByProjection(CurrentFrame, LastFrame, th) (src/ORBmatcher.cc:1518-1631), camera fx = fy = 100,
+    cx = cy = 50, Tcw = [I | (0, 0, 1)], th = 5.
+    point 0 (0.25, 0.5, 1) -> camera (0.25, 0.5, 2) -> u = 100*0.25*0.5 + 50 = 62.5, v = 75; octave 1:
+            radius = 5 * 1.2f = 6.0 (the product is an exact tie, rounded to even), levels 0..2
+    point 1 skipped (no map point / outlier);  point 2 (-1, 0, 1) -> u = 0: "u < mnMinX" is false, kept; octave 0
+    point 3 (13, 0, 1) -> u = 700 > mnMaxX: dropped."""
+    sf = np.array([1.0, 1.2, 1.44], np.float32)
+    T = np.eye(4, dtype=np.float32)
+    T[2, 3] = 1.0
+    last = kps(orbref, [(0, 0, 1, 10.0), (0, 0, 0, 0.0), (0, 0, 0, 200.0), (0, 0, 0, 0.0)])
+    pos = np.array([[0.25, 0.5, 1], [0, 0, 1], [-1, 0, 1], [13, 0, 1]], np.float32)
+    dlast = np.stack([bits(0), bits(0), bits(10), bits(0)])
+    #             a: in window   b: level 3     c: taken        d: 6.5 px off   e: near point 2
+    cur = kps(orbref, [(60, 75, 1), (64, 79, 3), (68, 75, 1), (69, 75, 1), (2, 52, 1)])
+    dcur = np.stack([bits(3), bits(0), bits(1), bits(0), bits(110)])
+    taken = np.array([0, 0, 1, 0, 0], np.uint8)
+    for ori in (False, True):
+        n, match, probes = orbref.sbp_last_frame(cur, dcur, B640, taken, (100.0, 100.0, 50.0, 50.0), T, sf, last, dlast,
+                                                 [0, 1, 0, 0], pos, 5.0, ori)
+        assert list(probes["valid"]) == [1, 0, 1, 0]
+        assert (probes["u"][0], probes["v"][0], probes["r"][0]) == (62.5, 75.0, 6.0)
+        assert (probes["min_level"][0], probes["max_level"][0], probes["angle"][0]) == (0, 2, 10.0)
+        assert (probes["u"][2], probes["v"][2], probes["r"][2], probes["min_level"][2], probes["max_level"][2]) == (0.0, 50.0, 5.0, -1, 1)
+        # point 0: a (3 bits) wins, c is taken, b and d are outside; point 2: e at exactly TH_HIGH = 100 is accepted
+        assert n == 2 and list(match) == [0, -1, -1, -1, 2]
+    # one bit further is past TH_HIGH
+    dcur[4] = bits(111)
+    n, match, _ = orbref.sbp_last_frame(cur, dcur, B640, taken, (100.0, 100.0, 50.0, 50.0), T, sf, last, dlast, [0, 1, 0, 0],
+                                        pos, 5.0, False)
+    assert n == 1 and list(match) == [0, -1, -1, -1, -1]
+
+
+def test_projection_local_map_by_hand(orbref):
+    """SearchByProjection(Frame&, vector<MapPoint*>&, th) (src/ORBmatcher.cc:52-128), th = 1, ratio 0.8.
+    points 0, 1: both project to (100, 100), level 2 (levels 1..2, radius 2.5 * 1.44): point 0 takes a (10 bits; the
+            second best c is on another level, so no ratio test); point 1 then sees b (12, level 2) and c (11, level 1):
+            takes c, again across levels
+    point 2: d, e on one level at 10 and 11 bits: 10 > 0.8 * 11 -> rejected
+    point 3: f, g on one level at 8 and 11 bits: 8 <= 8.8 -> accepted
+    point 4: mTrackViewCos = 0.998f, which is greater than the double 0.998: radius 2.5, h at 2.6 px stays outside
+    point 5: not in view; point 6: bad."""
+    sf = np.array([1.0, 1.2, 1.44, 1.728], np.float32)
+    cur = kps(orbref, [(100, 100, 2), (101, 100, 2), (102, 100, 1), (200, 200, 3), (201, 200, 3), (300, 300, 3), (301, 300, 3),
+                       (402.6, 400, 0)])
+    dcur = np.stack([bits(10), bits(12), bits(11), bits(10), bits(11), bits(8), bits(11), bits(0)])
+    px = np.array([100, 100, 200, 300, 400, 100, 100], np.float32)
+    level = np.array([2, 2, 3, 3, 0, 2, 2], np.int32)
+    cosv = np.array([0.999, 0.999, 0.999, 0.999, 0.998, 0.999, 0.999], np.float32)
+    in_view = np.array([1, 1, 1, 1, 1, 0, 1], np.uint8)
+    bad = np.array([0, 0, 0, 0, 0, 0, 1], np.uint8)
+    mp_desc = np.stack([bits(0)] * 7)
+    n, match, probes = orbref.sbp_local_map(cur, dcur, B640, sf, None, in_view, bad, level, cosv, px, px, mp_desc, 1.0, 0.8)
+    assert list(probes["valid"]) == [1, 1, 1, 1, 1, 0, 0]
+    assert probes["r"][0] == np.float32(2.5) * sf[2] and probes["r"][4] == 2.5
+    assert (probes["min_level"][4], probes["max_level"][4]) == (-1, 0)
+    assert n == 3 and list(match) == [0, -1, 1, -1, -1, 3, -1, -1]
+    # th = 3 multiplies the radius: point 4 now reaches h
+    n, match, probes = orbref.sbp_local_map(cur, dcur, B640, sf, None, in_view, bad, level, cosv, px, px, mp_desc, 3.0, 0.8)
+    assert probes["r"][4] == 7.5 and match[7] == 4
+
+
+def test_projection_sim3_and_keyframe_by_hand(orbref):
+    """Scw = 2 * [I | (0, 0, 0.5)]: scw = 2, Rcw = I, tcw = (0, 0, 0.5), Ow = (0, 0, -0.5).
+    point (0.5, 0, 1.5) -> camera (0.5, 0, 2) -> u = 100*0.25 + 50 = 75, v = 50; PO = (0.5, 0, 2), dist = sqrt(4.25);
+    minDistance = dist / 1.3 -> ratio 1.3 -> lower_bound over (1, 1.2, 1.44) = level 2; radius = 10 * 1.44;
+    the keypoint test is a plain level range 1..2 after an unfiltered KeyFrame::GetFeaturesInArea."""
+    sf = np.array([1.0, 1.2, 1.44], np.float32)
+    S = np.eye(4, dtype=np.float32) * 2
+    S[3, 3] = 1
+    S[2, 3] = 1.0
+    pos = np.array([[0.5, 0, 1.5]], np.float32)
+    dist = np.float32(np.sqrt(4.25))
+    min_d = np.array([dist / np.float32(1.3)], np.float32)
+    max_d = min_d * 10
+    normal = np.array([[0, 0, 1]], np.float32)  # PO.n = 2 >= 0.5 * dist
+    cur = kps(orbref, [(75, 50, 0), (80, 55, 1), (76, 50, 2)])
+    dcur = np.stack([bits(0), bits(20), bits(21)])
+    K = (100.0, 100.0, 50.0, 50.0)
+    n, match, probes = orbref.sbp_sim3(cur, dcur, B640, K, sf, S, None, [0], pos, normal, min_d, max_d, bits(0)[None], 10)
+    assert (probes["u"][0], probes["v"][0], probes["min_level"][0], probes["max_level"][0]) == (75.0, 50.0, 1, 2)
+    assert probes["r"][0] == np.float32(10) * sf[2]
+    assert n == 1 and list(match) == [-1, 0, -1]  # level 0 is out of range; 20 bits = TH_LOW accepted, 21 would not be
+    n, match, _ = orbref.sbp_sim3(cur, dcur, B640, K, sf, S, [0, 1, 0], [0], pos, normal, min_d, max_d, bits(0)[None], 10)
+    assert n == 0 and list(match) == [-1, -1, -1]  # the 20-bit feature is already matched; the 21-bit one is too far
+    # viewing angle: PO.n < 0.5 * dist drops the point; so does a depth outside [minDistance, maxDistance]
+    n, _, probes = orbref.sbp_sim3(cur, dcur, B640, K, sf, S, None, [0], pos, np.array([[1, 0, 0]], np.float32), min_d, max_d,
+                                   bits(0)[None], 10)
+    assert n == 0 and probes["valid"][0] == 0
+    n, _, probes = orbref.sbp_sim3(cur, dcur, B640, K, sf, S, None, [0], pos, normal, min_d * 3, max_d * 3, bits(0)[None], 10)
+    assert n == 0 and probes["valid"][0] == 0
+    # the relocalisation overload on the same geometry (Tcw = [I | (0, 0, 0.5)]): levels 1..3, threshold ORBdist
+    T = np.eye(4, dtype=np.float32)
+    T[2, 3] = 0.5
+    n, match, probes = orbref.sbp_keyframe(cur, dcur, B640, None, K, T, sf, [0], pos, min_d, bits(0)[None], [30.0], 10.0, 20, False)
+    assert (probes["u"][0], probes["v"][0], probes["min_level"][0], probes["max_level"][0], probes["angle"][0]) == (75.0, 50.0, 1, 3, 30.0)
+    assert n == 1 and list(match) == [-1, 0, -1]
+    n, match, _ = orbref.sbp_keyframe(cur, dcur, B640, None, K, T, sf, [0], pos, min_d, bits(0)[None], [30.0], 10.0, 19, False)
+    assert n == 0
+
+
+def test_projection_frame_to_frame_by_hand(orbref):
+    """SearchByProjection(F1, F2, windowSize, ...) (src/ORBmatcher.cc:530-605): same-level window, ratio with <=."""
+    T = np.eye(4, dtype=np.float32)
+    K = (100.0, 100.0, 50.0, 50.0)
+    kp1 = kps(orbref, [(0, 0, 1), (0, 0, 1), (0, 0, 2)])
+    pos1 = np.array([[0.5, 0.5, 1], [0.5, 0.5, 1], [2, 2, 1]], np.float32)  # -> (100, 100), (100, 100), (250, 250)
+    d1 = np.stack([bits(0), bits(0), bits(0)])
+    kp2 = kps(orbref, [(101, 100, 1), (99, 100, 1), (250, 250, 1), (251, 250, 2)])
+    d2 = np.stack([bits(8), bits(10), bits(0), bits(30)])
+    # point 0: 8 vs 10 bits, 8 <= 10 * 0.8 -> takes feature 0; point 1: only feature 1 is left (second = INT_MAX) -> takes it;
+    # point 2 (level 2): feature 2 is on level 1, feature 3 at 30 bits -> accepted
+    n, match, probes = orbref.sbp_frames(kp1, d1, [0, 0, 0], pos1, T, K, kp2, d2, B640, None, 5, 0.8)
+    assert (probes["u"][2], probes["v"][2], probes["r"][2], probes["min_level"][2], probes["max_level"][2]) == (250.0, 250.0, 5.0, 2, 2)
+    assert n == 3 and list(match) == [0, 1, -1, 2]
+    d2[1] = bits(9)  # 8 > 9 * 0.8: point 0 is rejected, point 1 sees the same pair and is rejected as well
+    n, match, _ = orbref.sbp_frames(kp1, d1, [0, 0, 0], pos1, T, K, kp2, d2, B640, None, 5, 0.8)
+    assert n == 1 and list(match) == [-1, -1, -1, 2]
