@@ -479,9 +479,50 @@ def windowed_leg(orb, torch, dev, orbref):
                                        2**31 - 1, m_win.mfNNratio, True)
         t_w += time.perf_counter() - t0
         ok = ok and np.array_equal(r12, m12[f, :k]) and np.array_equal(r21, m21[f, :k])
+    # SearchByProjection(CurrentFrame, LastFrame, th = 15): one probe per keypoint of F1 at its own position
+    # (identity motion), radius 15 * scale[octave], levels octave-1..octave+1, best distance <= TH_HIGH, rotation check
+    sf = np.ones(8, np.float32)
+    for l in range(1, 8):
+        sf[l] = sf[l - 1] * np.float32(1.2)
+    k1f = kp1.view(torch.float32).view(b, nf, 7)
+    octv = kp1.view(torch.int32).view(b, nf, 7)[:, :, 5]
+    pr = torch.zeros((b, nf, 8), dtype=torch.float32, device=cuda)
+    pri = pr.view(torch.int32)
+    pr[:, :, 0:2] = k1f[:, :, 0:2]
+    pr[:, :, 2] = torch.from_numpy(sf * np.float32(15.0)).to(cuda)[octv.long()]
+    pri[:, :, 3] = octv - 1
+    pri[:, :, 4] = octv + 1
+    pr[:, :, 5] = k1f[:, :, 3]
+    pri[:, :, 6] = 1
+    probes = pr.view(torch.uint8).view(b, nf, 32)
+    m_proj = orb.ORBmatcher(0.9, True, device=dev)
+    fn = lambda: m_proj.SearchByProjection(F2, probes, d1, n, orb.ORBmatcher.PROJ_BEST, th_dist=100)  # noqa: E731
+    fn()
+    ts = []
+    for _ in range(3):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        nm_p, mo = fn()
+        torch.cuda.synchronize(dev)
+        ts.append(time.perf_counter() - t0)
+    out["search_by_projection_last_frame_th15"] = {
+        "frames_per_sec": round(b / float(np.median(ts)), 1), "ms_per_%d_frames" % b: round(float(np.median(ts)) * 1e3, 3),
+        "mean_matches_per_frame": round(float(nm_p.float().mean().item()), 1)}
+    mo = mo[:4].cpu().numpy()
+    t_p = 0.0
+    ident = np.eye(4, dtype=np.float32)
+    for f in range(4):
+        k = int(hn[f])
+        pos = np.stack([hk1[f, :k]["x"], hk1[f, :k]["y"], np.ones(k, np.float32)], 1)
+        t0 = time.perf_counter()
+        rn, rmo, _ = orbref.sbp_last_frame(hk2[f, :k], hd2[f, :k], bounds, None, (1.0, 1.0, 0.0, 0.0), ident, sf, hk1[f, :k],
+                                           hd1[f, :k], np.zeros(k, np.uint8), pos, 15.0, True)
+        t_p += time.perf_counter() - t0
+        ok = ok and np.array_equal(rmo, mo[f, :k]) and rn == int(nm_p[f].item())
     out["frame_grid_ms_per_%d_frames" % b] = round(t_grid * 1e3, 3)
     out["cpu_oracle_1_thread_pairs_per_sec"] = {"search_for_initialization_w100": round(4 / t_i, 1),
-                                                "window_search_w100": round(4 / t_w, 1)}
+                                                "window_search_w100": round(4 / t_w, 1),
+                                                "search_by_projection_last_frame_th15": round(4 / t_p, 1)}
     out["parity_first_4_pairs"] = bool(ok)
     return out
 
