@@ -286,6 +286,25 @@ int orbhip_window_search(orbhip_matcher* m, const OrbKeypoint* kp1, const uint8_
 int orbhip_distinctive_descriptors_device(orbhip_matcher* m, const uint8_t* d_desc, const int32_t* d_start,
                                           int npoints, int32_t* d_best_idx, int32_t* d_best_median);
 
+/* ---- Keypoint undistortion -----------------------------------------------------------------------
+ * Camera of a frame as the reference holds it: mK (fx, fy, cx, cy; CV_32F) and mDistCoef (k1, k2, p1,
+ * p2; CV_32F), src/Tracking.cc (settings file) and include/Frame.h. */
+typedef struct OrbCamera {
+    float fx, fy, cx, cy;
+    float k1, k2, p1, p2;
+} OrbCamera;
+/* Replaces Frame::UndistortKeyPoints (src/Frame.cc:290-320) for `batch` frames: d_kp_un[f*cap + i] is
+ * keypoint record i of frame f with pt replaced by cv::undistortPoints(pt, mK, mDistCoef, Mat(), mK) —
+ * double arithmetic, five iterations, as OpenCV 2.4 evaluates it — or an unchanged copy when
+ * cam.k1 == 0 (:292-296).  In-place (d_kp_un == d_kp) is allowed.  Device pointers; asynchronous on
+ * the matcher's stream. */
+int orbhip_undistort_keypoints_device(orbhip_matcher* m, const OrbKeypoint* d_kp, const int32_t* d_n, int batch, int cap,
+                                      OrbCamera cam, OrbKeypoint* d_kp_un);
+/* Replaces Frame::ComputeImageBounds (src/Frame.cc:322-350): the bounds of the undistorted image from
+ * its four corners (floor / ceil of the float results), or {0, 0, cols, rows} when cam.k1 == 0.  Host
+ * computation; no GPU involved. */
+int orbhip_image_bounds(OrbCamera cam, int cols, int rows, OrbFrameBounds* out);
+
 /* ---- Bag-of-words transform (vocabulary tree) ----------------------------------------------------
  * The tree of Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h (Node, :296-330) as arrays in node-id
  * order, node 0 = root: parent[i] < i, the node's 32-byte descriptor, its weight (read at leaves).

@@ -748,4 +748,96 @@ int orbref_sbp_keyframe(const void* kp_cur, const uint8_t* desc_cur, int n_cur, 
     return nmatches;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// cv::undistortPoints(src, dst, cameraMatrix, distCoeffs, R = Mat(), P = cameraMatrix) as OpenCV 2.4's
+// cvUndistortPoints evaluates it (modules/imgproc/src/undistort.cpp; not part of the reference checkout,
+// restated from its published algorithm): everything in double, camera matrix and coefficients converted
+// from CV_32F, k[8] zero-filled past the coefficients given, iters = 5, RR = PP * identity by a 3x3 matrix
+// product, result stored as float.  Called by Frame::UndistortKeyPoints (src/Frame.cc:290-320) and
+// Frame::ComputeImageBounds (:322-350).
+namespace {
+
+void cv_undistort_points(const float* src_xy, float* dst_xy, int n, const float K[4] /*fx fy cx cy*/, const float* dist, int ndist) {
+    double A[3][3] = {{K[0], 0, K[2]}, {0, K[1], K[3]}, {0, 0, 1}};
+    double RR[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < ndist && i < 8; i++) k[i] = dist[i];
+    const int iters = ndist > 0 ? 5 : 1;
+    {
+        double PP[3][3], T[3][3];
+        memcpy(PP, A, sizeof(PP));
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                double s0 = 0;
+                for (int q = 0; q < 3; q++) s0 += PP[i][q] * RR[q][j];
+                T[i][j] = s0;
+            }
+        memcpy(RR, T, sizeof(RR));
+    }
+    const double fx = A[0][0], fy = A[1][1], ifx = 1. / fx, ify = 1. / fy, cx = A[0][2], cy = A[1][2];
+    for (int i = 0; i < n; i++) {
+        double x, y, x0, y0;
+        x = src_xy[2 * i];
+        y = src_xy[2 * i + 1];
+        x0 = x = (x - cx) * ifx;
+        y0 = y = (y - cy) * ify;
+        for (int j = 0; j < iters; j++) {
+            double r2 = x * x + y * y;
+            double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+            double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+            double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
+        double xx = RR[0][0] * x + RR[0][1] * y + RR[0][2];
+        double yy = RR[1][0] * x + RR[1][1] * y + RR[1][2];
+        double ww = 1. / (RR[2][0] * x + RR[2][1] * y + RR[2][2]);
+        x = xx * ww;
+        y = yy * ww;
+        dst_xy[2 * i] = (float)x;
+        dst_xy[2 * i + 1] = (float)y;
+    }
+}
+
+}  // namespace
+
+// Frame::UndistortKeyPoints: kp_un = kp with pt undistorted, or a plain copy when mDistCoef(0) == 0.
+void orbref_undistort_keypoints(const void* kp, int n, const float K[4], const float dist[4], void* kp_un) {
+    const Kp* in = (const Kp*)kp;
+    Kp* out = (Kp*)kp_un;
+    if (dist[0] == 0.0) {
+        for (int i = 0; i < n; i++) out[i] = in[i];
+        return;
+    }
+    std::vector<float> mat(2 * (size_t)n + 2);
+    for (int i = 0; i < n; i++) {
+        mat[2 * i] = in[i].x;
+        mat[2 * i + 1] = in[i].y;
+    }
+    cv_undistort_points(mat.data(), mat.data(), n, K, dist, 4);
+    for (int i = 0; i < n; i++) {
+        Kp k = in[i];
+        k.x = mat[2 * i];
+        k.y = mat[2 * i + 1];
+        out[i] = k;
+    }
+}
+
+// Frame::ComputeImageBounds: bounds[4] = mnMinX, mnMinY, mnMaxX, mnMaxY
+void orbref_image_bounds(const float K[4], const float dist[4], int cols, int rows, int32_t bounds[4]) {
+    if (dist[0] != 0.0) {
+        float mat[8] = {0.0f, 0.0f, (float)cols, 0.0f, 0.0f, (float)rows, (float)cols, (float)rows};
+        cv_undistort_points(mat, mat, 4, K, dist, 4);
+        bounds[0] = std::min(std::floor(mat[0]), std::floor(mat[4]));
+        bounds[2] = std::max(std::ceil(mat[2]), std::ceil(mat[6]));
+        bounds[1] = std::min(std::floor(mat[1]), std::floor(mat[3]));
+        bounds[3] = std::max(std::ceil(mat[5]), std::ceil(mat[7]));
+    } else {
+        bounds[0] = 0;
+        bounds[2] = cols;
+        bounds[1] = 0;
+        bounds[3] = rows;
+    }
+}
+
 }  // extern "C"

@@ -87,6 +87,10 @@ def lib():
         L.orbref_bow_score_l1.argtypes = [vp, vp, i32, vp, vp, i32]
         L.orbref_distinctive_descriptor.argtypes = [vp, i32, vp]
         L.orbref_window_search.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, f32, i32, vp]
+        L.orbref_undistort_keypoints.argtypes = [vp, i32, vp, vp, vp]
+        L.orbref_undistort_keypoints.restype = None
+        L.orbref_image_bounds.argtypes = [vp, vp, i32, i32, vp]
+        L.orbref_image_bounds.restype = None
         L.orbref_sbp_local_map.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, f32, f32, vp, vp]
         L.orbref_sbp_sim3.argtypes = [vp, vp, i32, vp, f32, f32, f32, f32, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp]
         L.orbref_sbp_frames.argtypes = [vp, vp, i32, vp, vp, vp, f32, f32, f32, f32, vp, vp, i32, vp, vp, i32, f32, vp, vp]
@@ -342,6 +346,23 @@ def sbp_keyframe(kp_cur, desc_cur, bounds, taken_cur, K, Tcw, scale_factors, ski
                                   len(sf), nkf, *[_p(a) for a in args], th, int(orb_dist), int(check_orientation), _p(out),
                                   _p(probes))
     return n, out[:len(kp_cur)].copy(), probes[:nkf].copy()
+
+
+def undistort_keypoints(kp, K, dist):
+    """Frame::UndistortKeyPoints: mvKeysUn from mvKeys, K = (fx, fy, cx, cy), dist = (k1, k2, p1, p2)."""
+    kp = np.ascontiguousarray(kp, dtype=KP_DTYPE)
+    out = np.zeros(max(len(kp), 1), KP_DTYPE)
+    k, d = _f32(K), _f32(dist)
+    lib().orbref_undistort_keypoints(_p(kp), len(kp), _p(k), _p(d), _p(out))
+    return out[:len(kp)].copy()
+
+
+def image_bounds(K, dist, cols, rows):
+    """Frame::ComputeImageBounds: [mnMinX, mnMinY, mnMaxX, mnMaxY]."""
+    b = np.zeros(4, np.int32)
+    k, d = _f32(K), _f32(dist)
+    lib().orbref_image_bounds(_p(k), _p(d), int(cols), int(rows), _p(b))
+    return [int(v) for v in b]
 
 
 def distinctive_descriptor(desc):

@@ -39,6 +39,11 @@ def _preload_torch_hip_runtime():
             pass
 
 
+class OrbCamera(C.Structure):
+    """mK (fx, fy, cx, cy) and mDistCoef (k1, k2, p1, p2) of a frame, both CV_32F in the reference."""
+    _fields_ = [(k, C.c_float) for k in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2")]
+
+
 class OrbFrameBounds(C.Structure):
     """Frame::mnMinX, mnMinY, mnMaxX, mnMaxY (src/Frame.cc:322-350)."""
     _fields_ = [("min_x", C.c_int32), ("min_y", C.c_int32), ("max_x", C.c_int32), ("max_y", C.c_int32)]
@@ -108,6 +113,8 @@ def lib():
     L.orbhip_search_by_projection_device.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, OrbFrameBounds,
                                                      vp, i32, f32, i32, i32, vp, vp]
     L.orbhip_search_by_projection.argtypes = [vp, vp, vp, i32, vp, vp, i32, OrbFrameBounds, vp, i32, f32, i32, i32, vp, vp]
+    L.orbhip_undistort_keypoints_device.argtypes = [vp, vp, vp, i32, i32, OrbCamera, vp]
+    L.orbhip_image_bounds.argtypes = [OrbCamera, i32, i32, C.POINTER(OrbFrameBounds)]
     L.orbhip_device_count.argtypes = []
     L.orbhip_version.restype = C.c_char_p
     L.orbhip_last_error.restype = C.c_char_p

@@ -20,6 +20,31 @@ PROBE_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("r", "<f4"), ("min_level", 
                         ("angle", "<f4"), ("valid", "<i4"), ("reserved", "<i4")])
 
 
+def UndistortKeyPoints(matcher, kp, n, K, dist, out=None):
+    """Frame::UndistortKeyPoints (src/Frame.cc:290-320) for a batch of frames.  kp: CUDA tensor of keypoint
+    records [batch, cap] (28 B each), n: int32 [batch], K = (fx, fy, cx, cy), dist = (k1, k2, p1, p2).
+    Returns mvKeysUn as a tensor shaped like kp (`out` may be kp itself)."""
+    import torch
+    assert kp.is_cuda and kp.is_contiguous() and n.is_cuda and n.dtype == torch.int32
+    batch = int(n.shape[0])
+    cap = kp.numel() * kp.element_size() // 28 // max(batch, 1)
+    out = torch.empty_like(kp) if out is None else out
+    cam = _lib.OrbCamera(*[float(v) for v in K], *[float(v) for v in dist])
+    torch.cuda.synchronize()
+    _lib.check(_lib.lib().orbhip_undistort_keypoints_device(matcher._h, kp.data_ptr(), n.data_ptr(), batch, cap, cam,
+                                                            out.data_ptr()))
+    matcher.synchronize()
+    return out
+
+
+def ComputeImageBounds(K, dist, cols, rows):
+    """Frame::ComputeImageBounds (src/Frame.cc:322-350): [mnMinX, mnMinY, mnMaxX, mnMaxY]."""
+    cam = _lib.OrbCamera(*[float(v) for v in K], *[float(v) for v in dist])
+    b = _lib.OrbFrameBounds()
+    _lib.check(_lib.lib().orbhip_image_bounds(cam, int(cols), int(rows), b))
+    return [b.min_x, b.min_y, b.max_x, b.max_y]
+
+
 class FrameBatch:
     """`batch` frames: keypoint records [batch, cap] (28 B each, as the extractor writes them),
     descriptors [batch, cap, 32] u8, counts [batch] i32 — torch CUDA tensors — plus the image bounds

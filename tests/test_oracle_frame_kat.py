@@ -305,3 +305,44 @@ def test_projection_frame_to_frame_by_hand(orbref):
     d2[1] = bits(9)  # 8 > 9 * 0.8: point 0 is rejected, point 1 sees the same pair and is rejected as well
     n, match, _ = orbref.sbp_frames(kp1, d1, [0, 0, 0], pos1, T, K, kp2, d2, B640, None, 5, 0.8)
     assert n == 1 and list(match) == [-1, -1, -1, 2]
+
+
+def test_undistort_points_known_answers(orbref):
+    """cv::undistortPoints as used by Frame::UndistortKeyPoints / ComputeImageBounds (src/Frame.cc:290-350).
+    (1) the principal point has x = y = 0 and stays put; (2) k1 == 0 copies the keypoints whatever the other
+    coefficients say (:292-296); (3) a point pushed through the forward Brown model comes back (five fixed-point
+    iterations: 1e-3 px at mild distortion); (4) a pure radial k1 with y = 0: one iteration by hand."""
+    K = (500.0, 500.0, 320.0, 240.0)
+    kp = kps(orbref, [(320, 240), (100, 50), (600, 400)])
+    kp["response"], kp["size"] = [3, 4, 5], 31
+    un = orbref.undistort_keypoints(kp, K, (0.1, 0.01, 0.001, -0.002))
+    assert (un["x"][0], un["y"][0]) == (320.0, 240.0)
+    assert list(un["response"]) == [3, 4, 5] and list(un["octave"]) == list(kp["octave"])
+    same = orbref.undistort_keypoints(kp, K, (0.0, 0.5, 0.1, 0.1))
+    assert np.array_equal(same.view(np.uint32), kp.view(np.uint32))
+    # forward model in double
+    k1, k2, p1, p2 = -0.12, 0.03, 0.0007, -0.0004
+    rng = np.random.default_rng(3)
+    xn, yn = rng.uniform(-0.5, 0.5, 200), rng.uniform(-0.4, 0.4, 200)
+    r2 = xn * xn + yn * yn
+    cd = 1 + k1 * r2 + k2 * r2 * r2
+    xd = xn * cd + 2 * p1 * xn * yn + p2 * (r2 + 2 * xn * xn)
+    yd = yn * cd + p1 * (r2 + 2 * yn * yn) + 2 * p2 * xn * yn
+    kpd = kps(orbref, list(zip(500 * xd + 320, 500 * yd + 240)))
+    un = orbref.undistort_keypoints(kpd, K, (k1, k2, p1, p2))
+    assert np.abs(un["x"] - (500 * xn + 320)).max() < 2e-3 and np.abs(un["y"] - (500 * yn + 240)).max() < 2e-3
+    # by hand: K = (1, 1, 0, 0), k1 = 0.5, point (0.5, 0): x <- x0 / (1 + k1 x^2), five times from x = x0
+    x = 0.5
+    for _ in range(5):
+        x = 0.5 * (1.0 / (1.0 + 0.5 * (x * x)))
+    un = orbref.undistort_keypoints(kps(orbref, [(0.5, 0.0)]), (1.0, 1.0, 0.0, 0.0), (0.5, 0.0, 0.0, 0.0))
+    assert un["x"][0] == np.float32(x) and un["y"][0] == 0.0
+
+
+def test_image_bounds_known_answers(orbref):
+    K = (500.0, 500.0, 320.0, 240.0)
+    assert orbref.image_bounds(K, (0.0, 0.3, 0.0, 0.0), 640, 480) == [0, 0, 640, 480]
+    # barrel distortion (k1 < 0) pushes the undistorted corners outwards, symmetrically for a centred camera
+    b = orbref.image_bounds(K, (-0.2, 0.0, 0.0, 0.0), 640, 480)
+    assert b[0] < 0 and b[1] < 0 and b[2] > 640 and b[3] > 480
+    assert b[0] == -(b[2] - 640) and b[1] == -(b[3] - 480)
