@@ -274,3 +274,27 @@ def test_cells_past_the_border_are_rejected(orb, orbref, synth):
     assert ei.value.code == -5 and "border" in str(ei.value)
     with pytest.raises(RuntimeError):
         orbref.RefExtractor(858, 1.3, 1, 1, 43)(synth.synth_image(807, 139, 7533))
+
+
+@pytest.mark.parametrize("kind", ["noise", "noise_binary", "checker1", "checker3", "dots7", "ramp"])
+@pytest.mark.parametrize("nf,th,score", [(3000, 5, 1), (1000, 20, 0)])
+def test_dense_corner_images(orb, orbref, kind, nf, th, score):
+    """Corner densities far above natural images (survivor lists, corner lists and cell lists at their
+    fullest; heavy score ties in the selection)."""
+    w, h = 640, 480
+    rng = np.random.default_rng(0)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = {
+        "noise": lambda: rng.integers(0, 256, (h, w), dtype=np.uint8),
+        "noise_binary": lambda: (rng.integers(0, 2, (h, w)) * 255).astype(np.uint8),
+        "checker1": lambda: (((xx + yy) & 1) * 255).astype(np.uint8),
+        "checker3": lambda: ((((xx // 3) + (yy // 3)) & 1) * 255).astype(np.uint8),
+        "dots7": lambda: np.where((xx % 7 == 3) & (yy % 7 == 3), 255, 0).astype(np.uint8),
+        "ramp": lambda: ((xx * 3 + yy * 5) % 256).astype(np.uint8),
+    }[kind]()
+    dev = orb.ORBextractor(nf, 1.2, 8, score, th, device=0, max_width=w, max_height=h)
+    ref = orbref.RefExtractor(nf, 1.2, 8, score, th)
+    rkp, rdesc = ref(img)
+    dkp, ddesc = dev(img)
+    _assert_same(rkp, rdesc, dkp, ddesc)
+    assert len(rkp) > 500
