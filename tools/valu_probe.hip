@@ -147,6 +147,20 @@ PROBE3(or3, "v_or3_b32")
 PROBE3(min3_f32, "v_min3_f32")
 PROBE3(pk_mad_u16, "v_pk_mad_u16")
 PROBE3(cvt_pk_u8_f32, "v_cvt_pk_u8_f32")
+PROBE2(max_u16, "v_max_u16")
+PROBE2(min_i16, "v_min_i16")
+PROBE2(max_f16, "v_max_f16")
+PROBE2(min_f16, "v_min_f16")
+PROBE2(sub_u16, "v_sub_u16")
+PROBE2(pk_max_f16, "v_pk_max_f16")
+PROBE2(pk_min_f16, "v_pk_min_f16")
+PROBE2(pk_add_f16, "v_pk_add_f16")
+PROBE3(min3_f16, "v_min3_f16")
+PROBE3(max3_f16, "v_max3_f16")
+PROBE3(min3_u16, "v_min3_u16")
+PROBE3(max3_i16, "v_max3_i16")
+PROBE3(med3_f16, "v_med3_f16")
+PROBE3(max3_u32, "v_max3_u32")
 PROBE1(mov_b32, "v_mov_b32")
 PROBE1(cvt_f32_i32, "v_cvt_f32_i32")
 PROBE1(cvt_f32_ubyte0, "v_cvt_f32_ubyte0")
@@ -196,6 +210,8 @@ int main() {
     RUN(min3_i32); RUN(max3_i32); RUN(med3_i32); RUN(perm_b32); RUN(mad_i32_i24); RUN(mad_u32_u24);
     RUN(lshl_add_u32); RUN(add3_u32); RUN(and_or_b32); RUN(lshl_or_b32); RUN(bfe_u32); RUN(alignbyte);
     RUN(dot4_u32_u8); RUN(dot2_u32_u16); RUN(sad_u8); RUN(sad_u32); RUN(fma_f32); RUN(xad_u32); RUN(max_f32); RUN(mul_hi_u32); RUN(mul_hi_u32_u24); RUN(lshlrev); RUN(or_b32); RUN(ashrrev); RUN(cndmask); RUN(add_f16); RUN(pk_fma_dummy); RUN(mad_u32_u16); RUN(add_lshl); RUN(or3); RUN(min3_f32); RUN(pk_mad_u16); RUN(cvt_pk_u8_f32);
+    RUN(max_u16); RUN(min_i16); RUN(max_f16); RUN(min_f16); RUN(sub_u16); RUN(pk_max_f16); RUN(pk_min_f16); RUN(pk_add_f16);
+    RUN(min3_f16); RUN(max3_f16); RUN(min3_u16); RUN(max3_i16); RUN(med3_f16); RUN(max3_u32);
     RUN(mov_b32); RUN(cvt_f32_i32); RUN(cvt_f32_ubyte0); RUN(rndne_f32); RUN(rcp_f32); RUN(ffbl);
     RUN(mul_f64); RUN(add_f64); RUN(pk_mul_f32); RUN(pk_add_f32);
     RUN(ds_read_b32); RUN(ds_read_u8); RUN(ds_read_u8_spread); RUN(ds_read_u16);
