@@ -35,15 +35,9 @@ namespace orbk {
 #define FC_WCAP (2 * 256 + 64)  // per-wave list: survivors of two rows + a carried-over partial chunk
 #define FC_QCAP (FC_WAVES * FC_WCAP)
 
-typedef short short2v __attribute__((ext_vector_type(2)));
-
 __device__ __forceinline__ int lane_prefix(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
 }
-__device__ __forceinline__ short2v as_s2(uint32_t v) { return __builtin_bit_cast(short2v, v); }
-__device__ __forceinline__ uint32_t as_u32(short2v v) { return __builtin_bit_cast(uint32_t, v); }
-// (byte lo | byte hi << 16) of two source bytes; selector bytes 0-3 pick from b, 4-7 from a, 0x0c = 0
-#define PAIR(a, b, sel) as_s2(__builtin_amdgcn_perm((a), (b), (sel)))
 
 // Inclusive prefix sum over the 64 lanes with DPP row shifts and broadcasts (no LDS).
 __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
@@ -63,30 +57,44 @@ __device__ __forceinline__ uint32_t nb_max8(const uint8_t* __restrict__ p, int s
     return max(max(a, b), max((uint32_t)p[-1], (uint32_t)p[1]));
 }
 
-// Compass quick test of the four pixels of group gg in examined row r.  Bits 15/31 of z0 and z1
-// are clear for pixels 0/1 and 2/3 that pass.
-__device__ __forceinline__ void quick_row(const uint8_t* __restrict__ imgb, int pitch, int gg, int r, short2v thr1,
-                                          short2v nthr1, uint32_t& z0, uint32_t& z1) {
+// Compass quick test of the four pixels of group gg in examined row r (a pixel can only be a corner
+// if, of the circle pixels straight above / below and left / right, one of each pair is brighter than
+// v + t, or one of each pair darker than v - t), with 32-bit add / subtract / logic only (the
+// instructions that issue at full rate on this chip), two pixels per operation: the even pixels (0, 2) and the odd pixels (1, 3) of a
+// group are kept as two 16-bit fields of one register.  With BT = 0x8000 + v + t per field, bit 15 of
+// BT - I says "I is not brighter than v + t"; with DK = 0x8000 + v - t - 1, bit 15 of DK - I says "I is
+// darker than v - t".  No field ever borrows from its neighbour (every difference stays within
+// 0x8000 +- 511).  A pixel passes iff (up or down) and (left or right) are brighter, or the same with
+// darker.  Returns the four pass bits of the group (bit j = pixel j).
+__device__ __forceinline__ uint32_t quick_row_swar(const uint8_t* __restrict__ imgb, int pitch, int gg, int r, uint32_t T0,
+                                                   uint32_t T1) {
     const uint32_t* row = (const uint32_t*)(imgb + (r + 3) * pitch) + gg;
     const uint32_t wl = row[-1], wm = row[0], wr = row[1];
     const uint32_t up = *(const uint32_t*)((const uint8_t*)row - 3 * pitch);
     const uint32_t dn = *(const uint32_t*)((const uint8_t*)row + 3 * pitch);
-    const short2v V0 = PAIR(wm, wm, 0x0c010c00u), V1 = PAIR(wm, wm, 0x0c030c02u);
-    const short2v U0 = PAIR(up, up, 0x0c010c00u), U1 = PAIR(up, up, 0x0c030c02u);
-    const short2v D0 = PAIR(dn, dn, 0x0c010c00u), D1 = PAIR(dn, dn, 0x0c030c02u);
-    const short2v E0 = PAIR(wr, wm, 0x0c040c03u), E1 = PAIR(wr, wr, 0x0c020c01u);
-    const short2v W0 = PAIR(wl, wl, 0x0c020c01u), W1 = PAIR(wm, wl, 0x0c040c03u);
-#define QTEST(V, U, D, E, W, z)                                                                                          \
-    {                                                                                                                    \
-        const short2v d0 = V - D, d8 = V - U, d4 = V - E, d12 = V - W;                                                   \
-        const short2v a = __builtin_elementwise_min(__builtin_elementwise_max(d0, d8), __builtin_elementwise_max(d4, d12)); \
-        const short2v b = __builtin_elementwise_max(__builtin_elementwise_min(d0, d8), __builtin_elementwise_min(d4, d12)); \
-        /* pass <=> a > tmin || b < -tmin <=> (a - (tmin+1)) >= 0 || ((-tmin-1) - b) >= 0 */                             \
-        z = as_u32(a - thr1) & as_u32(nthr1 - b);                                                                        \
+    const uint32_t M = 0x00ff00ffu, H = 0x80008000u;
+    const uint32_t ce = wm & M, co = (wm >> 8) & M;
+    const uint32_t ue = up & M, uo = (up >> 8) & M;
+    const uint32_t de = dn & M, dd = (dn >> 8) & M;
+    const uint32_t le = (wl >> 8) & M;                                        // left of pixels 0, 2: bytes 1, 3 of wl
+    const uint32_t lo = __builtin_amdgcn_alignbit(ce, wl & M, 16);            // left of pixels 1, 3: wl byte 2, wm byte 0
+    const uint32_t re = __builtin_amdgcn_alignbit((wr >> 8) & M, co, 16);     // right of pixels 0, 2: wm byte 3, wr byte 1
+    const uint32_t ro = wr & M;                                               // right of pixels 1, 3: wr bytes 0, 2
+#define QSWAR(C, U, D, L, R, P)                                                              \
+    {                                                                                        \
+        const uint32_t ch = (C) | H;                                                         \
+        const uint32_t bt = ch + T0, dk = ch - T1;                                           \
+        const uint32_t notbright = ((bt - (U)) & (bt - (D))) | ((bt - (L)) & (bt - (R)));    \
+        const uint32_t dark = ((dk - (U)) | (dk - (D))) & ((dk - (L)) | (dk - (R)));         \
+        P = (notbright ^ H) | dark;                                                          \
     }
-    QTEST(V0, U0, D0, E0, W0, z0);
-    QTEST(V1, U1, D1, E1, W1, z1);
-#undef QTEST
+    uint32_t pe, po;
+    QSWAR(ce, ue, de, le, re, pe);
+    QSWAR(co, uo, dd, lo, ro, po);
+#undef QSWAR
+    // bit 15 / 31 of pe: pixels 0 / 2; of po: pixels 1 / 3
+    const uint32_t x = ((pe >> 15) & 0x00010001u) | ((po >> 14) & 0x00020002u);
+    return (x | (x >> 14)) & 0xfu;
 }
 
 __global__ __launch_bounds__(FC_THREADS) void k_fast_cell(const uint8_t* __restrict__ pyr, const GeomDev* __restrict__ g,
@@ -169,8 +177,7 @@ __global__ __launch_bounds__(FC_THREADS) void k_fast_cell(const uint8_t* __restr
         if (tid == 0) cn = 0;
     }
     __syncthreads();
-    const short2v thr1 = {(short)(t + 1), (short)(t + 1)};
-    const short2v nthr1 = {(short)(-t - 1), (short)(-t - 1)};
+    const uint32_t T0 = (uint32_t)t * 0x00010001u, T1 = T0 + 0x00010001u;
 
     // ---- quick test + exact measure: every wave works through its own rows and its own list, no
     // block barrier until all rows are done.  A wave tests two rows, appends the survivors to its
@@ -180,12 +187,10 @@ __global__ __launch_bounds__(FC_THREADS) void k_fast_cell(const uint8_t* __restr
     int n = 0;
     for (int ra = 2 * wave; ra < ch; ra += 2 * FC_WAVES) {
         const int rb2 = ra + 1;
-        uint32_t za0 = 0xffffffffu, za1 = 0xffffffffu, zb0 = 0xffffffffu, zb1 = 0xffffffffu;
-        if (act) quick_row(imgb, pitch, gg, ra, thr1, nthr1, za0, za1);
-        if (act && rb2 < ch) quick_row(imgb, pitch, gg, rb2, thr1, nthr1, zb0, zb1);
         // per-lane pass nibbles (bit j = pixel j of the group passes and is an examined pixel)
-        const uint32_t nibA = ~(((za0 >> 15) & 1u) | ((za0 >> 30) & 2u) | ((za1 >> 13) & 4u) | ((za1 >> 28) & 8u)) & vnib;
-        const uint32_t nibB = ~(((zb0 >> 15) & 1u) | ((zb0 >> 30) & 2u) | ((zb1 >> 13) & 4u) | ((zb1 >> 28) & 8u)) & vnib;
+        uint32_t nibA = 0, nibB = 0;
+        if (act) nibA = quick_row_swar(imgb, pitch, gg, ra, T0, T1) & vnib;
+        if (act && rb2 < ch) nibB = quick_row_swar(imgb, pitch, gg, rb2, T0, T1) & vnib;
         // every lane appends its own survivors as one run per row: positions from one wave-wide prefix
         // sum of the per-lane counts (both rows packed in one register); each row stays in raster order
         const uint32_t cnt = (uint32_t)__popc(nibA) | ((uint32_t)__popc(nibB) << 16);
