@@ -214,3 +214,20 @@ def test_probe_argument_errors(orb):
         m.SearchByProjection(F, z, z, n, 7)
     nm, mo = m.SearchByProjection(F, z, z, n, orb.ORBmatcher.PROJ_BEST)
     assert int(nm[0]) == 0 and (mo.cpu().numpy() == -1).all()
+
+
+def test_probe_lists_longer_than_the_lds_run_buffer(orb, orbref):
+    """One level, a 200x150 frame and a radius that covers it: every probe's candidate list holds all of the
+    frame's ~5000 features (more than the 4096 entries staged in LDS at a time)."""
+    rng = np.random.default_rng(151)
+    T = pose(rng)
+    s = Scene(orbref, rng, 4200, 200, 150, T, ties=True)
+    s.kp["octave"] = 1
+    s.level[:] = 1
+    n = len(s.level)
+    kp_last = np.zeros(n, orbref.KP_DTYPE)
+    kp_last["octave"], kp_last["angle"] = s.level, s.angle
+    skip = (rng.random(n) < 0.1).astype(np.uint8)
+    r = orbref.sbp_last_frame(s.kp, s.desc, s.bounds, s.taken, s.K, T, SCALE, kp_last, s.mp_desc, skip, s.pos, 300.0, True)
+    assert len(s.kp) > 4096
+    assert run_device(orb, [s], [r + (s.mp_desc, s.taken)], orb.ORBmatcher.PROJ_BEST, th_dist=100, ori=True) > 500

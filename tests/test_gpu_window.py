@@ -276,3 +276,17 @@ def test_distinctive_descriptors(orb, orbref):
     big = rng.integers(0, 256, (129, 32), dtype=np.uint8)
     with pytest.raises(orb.OrbhipError):
         m.ComputeDistinctiveDescriptors(torch.from_numpy(big).cuda(), torch.tensor([0, 129], dtype=torch.int32).cuda())
+
+
+def test_candidate_lists_longer_than_the_lds_run_buffer(orb, orbref, matcher):
+    """5000 keypoints of one level inside a 200x150 frame and a window that covers the frame: every
+    candidate list holds all 5000 features, more than the 4096 entries the resolution kernels stage in
+    LDS, so they read the lists from global memory."""
+    w, h = 200, 150
+    fr, rng = frames_for(orbref, 61, [5000, 4500], w, h, levels=1, ties=True)
+    pairs, valids = [], []
+    for kp, de in fr:
+        pairs.append((kp, de) + moved(orbref, rng, kp, de, w, h, drop=0.0, rot=10.0))
+        valids.append((rng.random(len(kp)) < 0.9).astype(np.uint8))
+    assert _run_search_init(orb, orbref, matcher, pairs, [0, 0, w, h], 300, 0.9, True, cap=_pad_equal(pairs)) > 100
+    assert _run_window(orb, orbref, pairs, valids, [0, 0, w, h], 300, -1, INT_MAX, 0.8, True) > 100
