@@ -443,9 +443,11 @@ __global__ __launch_bounds__(256) void k_harris(const uint8_t* __restrict__ pyr,
 //   k_level_select  one workgroup per (level, frame): exclusive scan of nToRetain -> offsets,
 //                   gather of the retained prefixes in level coordinates, per-level selection by
 //                   one wave, level list and count out.
-// Lists larger than the LDS staging areas are selected in place in global memory by one lane
-// (introselect.h) — same results, only slower.
-#define SEL_WCAP 1024
+// Cell lists up to SEL_WCAP keys are staged in LDS; up to twice that the keys stay in global memory
+// and only the stop lists use LDS; larger lists (and level lists above SEL_LCAP) are selected in
+// place in global memory by one lane (introselect.h) — same results, only slower.  SEL_WCAP sets the
+// LDS per wave (4 KB at 512 keys) and with it the waves in flight of this latency-bound kernel.
+#define SEL_WCAP 512
 #define SEL_LCAP 4096
 
 __device__ __forceinline__ int block_sum(int v, int* red, int tid) {
@@ -539,6 +541,12 @@ __global__ __launch_bounds__(256) void k_cell_select(const GeomDev* __restrict__
         orbsel::wave_nth_element_desc(wbuf, n, kk, wl, wl + SEL_WCAP, lane);
         // the whole permuted list goes back, so the cell list stays a permutation of the candidates
         for (int i = lane; i < n; i += 64) list[i] = wbuf[i];
+    } else if (n <= 2 * SEL_WCAP) {
+        // keys stay in the cell's arena (cached global memory); the wave's whole LDS share holds the two
+        // stop lists: same wave-cooperative rounds, slower element access
+        uint16_t* lp = lists + wave * 2 * SEL_WCAP;           // 2 * SEL_WCAP entries
+        uint16_t* rp = (uint16_t*)(buf + wave * SEL_WCAP);    // SEL_WCAP keys = at least 2 * SEL_WCAP entries
+        orbsel::wave_nth_element_desc(list, n, kk, lp, rp, lane);
     } else if (lane == 0) {
         orbsel::nth_element_desc(list, n, kk);
     }

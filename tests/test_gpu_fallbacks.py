@@ -80,3 +80,24 @@ def test_corner_list_overflow_sweeps_every_pixel():
     env = dict(os.environ, ORBHIP_FC_CORNER_CAP="16")
     r = subprocess.run([sys.executable, "-c", _CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=110)
     assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_cell_selection_tiers(orb, orbref):
+    """Cell lists of up to 512 keys are selected in LDS, up to 1024 with the keys left in global memory, above
+    that by one lane: a noise frame at three feature counts puts cells in every tier (checked on the
+    per-cell candidate counts), in both key widths."""
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (480, 640), dtype=np.uint8)
+    seen = {"lds": 0, "global": 0, "lane": 0}
+    for nf in (250, 400, 800):
+        for score in (1, 0):
+            dev = orb.ORBextractor(nf, 1.2, 4, score, 20, device=0, max_width=640, max_height=480)
+            dkp, ddesc = dev(img)
+            _same(*orbref.RefExtractor(nf, 1.2, 4, score, 20)(img), dkp, ddesc)
+            c = np.concatenate([dev.tap_cells(3, 0, l) for l in range(4)])
+            r = np.concatenate([dev.tap_cells(4, 0, l) for l in range(4)])
+            sel = c > r
+            seen["lds"] += int(((c <= 512) & sel).sum())
+            seen["global"] += int(((c > 512) & (c <= 1024) & sel).sum())
+            seen["lane"] += int(((c > 1024) & sel).sum())
+    assert min(seen.values()) > 10, seen
