@@ -84,6 +84,35 @@ class FrameBatch:
         return cls(matcher, torch.from_numpy(kp).to(device), torch.from_numpy(de).to(device),
                    torch.from_numpy(n).to(device), bounds)
 
+    @classmethod
+    def from_images(cls, extractor, matcher, images, K=None, dist=None):
+        """The image part of the Frame constructor (src/Frame.cc:50-128) for a batch of equally sized frames that
+        are resident on the device: ORB extraction (:61), UndistortKeyPoints (:72), the image bounds
+        (:75-88, ComputeImageBounds) and the assignment of the undistorted keypoints to the grid (:110-124), with
+        no host round trip in between.  images: uint8 CUDA tensor [batch, rows, cols]; K = (fx, fy, cx, cy) and
+        dist = (k1, k2, p1, p2) as in mK / mDistCoef (None: no distortion).  The extractor must have been created
+        with max_batch >= 1 for this image size.  The result holds mvKeys in .kp_raw and mvKeysUn in .kp."""
+        import torch
+        assert images.is_cuda and images.dtype == torch.uint8 and images.dim() == 3 and images.is_contiguous()
+        b, rows, cols = (int(v) for v in images.shape)
+        cap = extractor.nfeatures
+        dev = images.device
+        kp = torch.zeros((b, cap, 7), dtype=torch.float32, device=dev)
+        desc = torch.zeros((b, cap, 32), dtype=torch.uint8, device=dev)
+        n = torch.zeros(b, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        extractor.extract_batch_device(images.data_ptr(), b, rows, cols, cols, rows * cols, kp.data_ptr(), desc.data_ptr(),
+                                       cap, n.data_ptr())
+        extractor.synchronize()
+        if K is None or dist is None or float(dist[0]) == 0.0:
+            kp_un, bounds = kp, [0, 0, cols, rows]
+        else:
+            kp_un = UndistortKeyPoints(matcher, kp, n, K, dist)
+            bounds = ComputeImageBounds(K, dist, cols, rows)
+        fb = cls(matcher, kp_un, desc, n, bounds)
+        fb.kp_raw = kp
+        return fb
+
     def ComputeBoW(self, voc, levelsup=4, node_cap=None):
         """Frame::ComputeBoW / KeyFrame::ComputeBoW (src/Frame.cc:281-288, src/KeyFrame.cc:82-91) for every frame
         of the batch: the vocabulary descent of all descriptors and the FeatureVector (mFeatVec) on the device.

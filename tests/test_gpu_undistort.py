@@ -43,3 +43,32 @@ def test_undistort_keypoints(orb, orbref, cam):
     d2 = d_kp.clone()
     orb.UndistortKeyPoints(m, d2, d_n, K, D, out=d2)
     assert torch.equal(inpl[5, :3000].view(torch.int32), d2[5, :3000].view(torch.int32))  # class_id -1 is a NaN as float
+
+
+def test_frame_constructor_path(orb, orbref, synth):
+    """Extraction -> UndistortKeyPoints -> image bounds -> grid, all on the device (the image part of
+    Frame::Frame, src/Frame.cc:50-128), against the same chain of oracle calls."""
+    import torch
+    w, h, nf = 640, 480, 800
+    K, D = CAMS[0]
+    imgs = synth.synth_batch(w, h, 3, first_idx=60)
+    ext = orb.ORBextractor(nf, 1.2, 8, 1, 20, device=0, max_width=w, max_height=h, max_batch=3)
+    m = orb.ORBmatcher(0.9, True)
+    fb = orb.FrameBatch.from_images(ext, m, torch.from_numpy(imgs).cuda(), K, D)
+    ref = orbref.RefExtractor(nf, 1.2, 8, 1, 20)
+    rb = orbref.image_bounds(K, D, w, h)
+    assert [fb.bounds.min_x, fb.bounds.min_y, fb.bounds.max_x, fb.bounds.max_y] == rb
+    for f in range(3):
+        rkp, rdesc = ref(imgs[f])
+        run = orbref.undistort_keypoints(rkp, K, D)
+        n = int(fb.n[f])
+        assert n == len(rkp)
+        got = np.ascontiguousarray(fb.kp[f, :n].cpu().numpy()).view(orbref.KP_DTYPE).reshape(n)
+        assert np.array_equal(got.view(np.uint32), run.view(np.uint32))
+        assert np.array_equal(fb.desc[f, :n].cpu().numpy(), rdesc)
+        cs, ci = orbref.frame_grid(run, rb)
+        ds, di = fb.grid(f)
+        assert np.array_equal(cs, ds) and np.array_equal(ci, di)
+    # no distortion: mvKeysUn is mvKeys and the bounds are the image
+    fb0 = orb.FrameBatch.from_images(ext, m, torch.from_numpy(imgs).cuda())
+    assert fb0.kp is fb0.kp_raw and [fb0.bounds.max_x, fb0.bounds.max_y] == [w, h]
