@@ -252,7 +252,9 @@ def main():
 
 
 def extra_legs(orb, torch, dev, threads):
-    """640x480 / 1000-feature extraction rate and Hamming kNN rate (not the headline value)."""
+    """Not the headline value: the 640x480 / 1000-feature and 1920x1080 / 4000-feature extraction rates (the
+    reference's own CPU-runnable case and the per-GPU shard of the 2048-frame configuration), the Hamming kNN
+    rates (4096 frame pairs; one map shard), the windowed / projection matchers and the BoW legs."""
     res = {}
     # extraction, 640x480, 1000 features, batch 256
     b = 256
@@ -274,9 +276,28 @@ def extra_legs(orb, torch, dev, threads):
                                    "cpu_oracle_%d_threads_frames_per_sec" % threads: round(cpuN, 2),
                                    "speedup_vs_1_thread": round(fps / cpu1, 1)}
     del wl
-    # Hamming kNN k=2: pairs of 2000 x 2000 descriptors
+    # extraction, 1920x1080, 4000 features, batch 256: the shard one GPU of eight owns in the 2048-frame
+    # configuration (32 distinct frames, repeated: host generation of 256 such frames would take longer than the run)
+    b3 = 256
+    f3 = np.concatenate([make_frames(orb.synth, 1920, 1080, 32, 300000)] * (b3 // 32))
+    wl = ExtractWorkload(orb, torch, dev, 1920, 1080, 4000, b3, first_idx=0, frames=f3)
+    for _ in range(2):
+        wl.step()
+    wl.sync()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        wl.step()
+    wl.sync()
+    dt3 = time.perf_counter() - t0
+    nl3 = wl.ext.GetLevels()
+    bytes3 = 5 * pyramid_pixels(wl.ext, nl3) + 60 * float(wl.d_n.float().mean().item())
+    res["extract_1920x1080_4000"] = {"frames_per_sec": round(b3 * 5 / dt3, 1), "batch": b3, "ms_per_step": round(dt3 / 5 * 1e3, 3),
+                                     "algorithmic_gb_per_sec": round(b3 * 5 / dt3 * bytes3 / 1e9, 1),
+                                     "keypoints_per_frame": round(float(wl.d_n.float().mean().item()), 1)}
+    del wl, f3
+    # Hamming kNN k=2: 4096 pairs of 2000 x 2000 descriptors (1.6384e10 comparisons)
     m = orb.ORBmatcher(0.6, True, device=dev)
-    pairs, nq, nt = 1024, 2000, 2000
+    pairs, nq, nt = 4096, 2000, 2000
     g = torch.Generator(device="cuda:%d" % dev)
     g.manual_seed(1)
     q = torch.randint(0, 256, (pairs, nq, 32), dtype=torch.uint8, device="cuda:%d" % dev, generator=g)
