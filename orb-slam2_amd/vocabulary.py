@@ -33,6 +33,56 @@ class ORBVocabulary:
         _lib.check(self._L.orbhip_vocabulary_create(C.byref(self._h), device, len(self.parent), _p(self.parent),
                                                     _p(self.desc), _p(self.weight), self.L))
 
+    @classmethod
+    def loadFromTextFile(cls, filename, device=0):
+        """The text format written by TemplatedVocabulary::saveToTextFile (TemplatedVocabulary.h:1424-1445) and read
+        by loadFromTextFile (:1337-1420), the format of ORBvoc.txt: a header "k L scoring weighting", then one line per
+        node in id order (the root has none): "parent isLeaf d0 ... d31 weight".  Nodes are numbered by line, children
+        attach in line order and words number the leaves in line order, as the reference does.  All 32 descriptor bytes
+        are read (the reference's v1 loader keeps only the last token of a line's descriptor, :1392-1394; a file it
+        wrote itself reloads here as saved).  Returns the vocabulary, or None for a file that fails the header check."""
+        with open(filename, "r") as f:
+            head = f.readline().split()
+            if len(head) < 4:
+                return None
+            k, L, scoring, weighting = (int(v) for v in head[:4])
+            if k < 0 or k > 20 or L < 1 or L > 10 or scoring < 0 or scoring > 5 or weighting < 0 or weighting > 3:
+                return None
+            rows = [ln.split() for ln in f if ln.strip()]
+        n = len(rows) + 1
+        parent = np.zeros(n, np.int32)
+        desc = np.zeros((n, 32), np.uint8)
+        weight = np.zeros(n, np.float64)
+        leaf = np.zeros(n, bool)
+        for i, t in enumerate(rows, start=1):
+            if len(t) != 35:
+                raise ValueError("%s: node line %d has %d fields, expected 35" % (filename, i, len(t)))
+            parent[i] = int(t[0])
+            if not 0 <= parent[i] < i:
+                raise ValueError("%s: node %d names parent %d" % (filename, i, parent[i]))
+            leaf[i] = int(t[1]) > 0
+            desc[i] = [int(v) for v in t[2:34]]
+            weight[i] = float(t[34])
+        has_child = np.zeros(n, bool)
+        has_child[parent[1:]] = True
+        if (leaf[1:] == has_child[1:]).any():
+            raise ValueError("%s: the isLeaf flags do not match the tree" % filename)
+        voc = cls(parent, desc, weight, L, weighting=weighting, scoring=scoring, device=device)
+        voc.k = k
+        return voc
+
+    def saveToTextFile(self, filename, k=None):
+        """TemplatedVocabulary::saveToTextFile (:1424-1445)."""
+        n = len(self.parent)
+        has_child = np.zeros(n, bool)
+        has_child[self.parent[1:]] = True
+        kk = k if k is not None else getattr(self, "k", int(np.bincount(self.parent[1:]).max()) if n > 1 else 0)
+        with open(filename, "w") as f:
+            f.write("%d %d  %d %d\n" % (kk, self.L, self.scoring, self.weighting))
+            for i in range(1, n):
+                f.write("%d %d %s %s\n" % (self.parent[i], 0 if has_child[i] else 1, " ".join(str(int(b)) for b in self.desc[i]),
+                                           repr(float(self.weight[i]))))
+
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
             self._L.orbhip_vocabulary_destroy(self._h)

@@ -142,3 +142,30 @@ def test_search_by_bow(orb, orbref, synth, kf_frame, ori):
         assert (m21[f] >= 0).sum() == (m12[f] >= 0).sum() == nm[f]
         total += rn
     assert total > 300
+
+
+def test_vocabulary_text_file_round_trip(orb, orbref, synth, tmp_path):
+    """ORBvoc.txt format (TemplatedVocabulary.h:1337-1445): save, reload, same tree and same transform."""
+    k, L = 5, 3
+    parent, desc, weight = synth.synth_vocabulary(k, L, seed=29)
+    voc = orb.ORBVocabulary(parent, desc, weight, L, weighting=1, scoring=0)
+    path = str(tmp_path / "voc.txt")
+    voc.saveToTextFile(path, k=k)
+    head = open(path).readline().split()
+    assert head == [str(k), str(L), "0", "1"]
+    v2 = orb.ORBVocabulary.loadFromTextFile(path)
+    # the root (node 0) is not in the file: its descriptor and weight are never read
+    assert np.array_equal(v2.parent, voc.parent) and np.array_equal(v2.desc[1:], voc.desc[1:])
+    assert np.array_equal(v2.weight[1:], voc.weight[1:])
+    assert (v2.L, v2.weighting, v2.scoring, v2.size()) == (L, 1, 0, voc.size())
+    m = orb.ORBmatcher()
+    rng = np.random.default_rng(31)
+    f = _features(rng, desc, 500)
+    a, b = voc.transform_features(m, f, 2), v2.transform_features(m, f, 2)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    ref = orbref.RefVocabulary(v2.parent, v2.desc, v2.weight, L, weighting=1, scoring=0)
+    assert all(np.array_equal(x, y) for x, y in zip(b, ref.transform_features(f, 2)))
+    # a file that fails the header check (src/.../TemplatedVocabulary.h:1358-1362) is refused
+    bad = tmp_path / "bad.txt"
+    bad.write_text("25 3 0 0\n")
+    assert orb.ORBVocabulary.loadFromTextFile(str(bad)) is None
