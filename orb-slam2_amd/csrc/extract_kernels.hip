@@ -681,7 +681,7 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 //
 // One thread owns a column of 4 pixels (one aligned dword) and walks BL_ROWS rows downwards.  Per
 // input row it loads three dwords (coalesced 256 B per wave), forms the four 7-tap row sums with
-// v_alignbyte + two v_dot4_u32_u8 each, and keeps the last seven rows of sums in registers (the
+// ten v_dot4_u32_u8 against tap words laid out per pixel, and keeps the last seven rows of sums in registers (the
 // row loop is fully unrolled so the ring slots are static); per output row the column pass is
 // 7 integer ops per pixel.  No LDS: neighbouring lanes' overlapping loads hit the vector L1.
 #define BL_ROWS 32
@@ -703,8 +703,13 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
     uint8_t* dst = blur + base;
     const int stride = L.stride;
     const int xl = max(dwx - 1, 0), xr = min(dwx + 1, ndw - 1);
-    const uint32_t tapsA = (uint32_t)t0 | ((uint32_t)t1 << 8) | ((uint32_t)t2 << 16) | ((uint32_t)t3 << 24);
-    const uint32_t tapsB = (uint32_t)t2 | ((uint32_t)t1 << 8) | ((uint32_t)t0 << 16);  // taps 4..6 = t2, t1, t0
+    // tap words: byte i of T?j multiplies byte i of the dword (taps 0..6 = t0 t1 t2 t3 t2 t1 t0)
+#define TAPW(b0, b1, b2, b3) ((uint32_t)(b0) | ((uint32_t)(b1) << 8) | ((uint32_t)(b2) << 16) | ((uint32_t)(b3) << 24))
+    const uint32_t TA0 = TAPW(0, t0, t1, t2), TB0 = TAPW(t3, t2, t1, t0);
+    const uint32_t TA1 = TAPW(0, 0, t0, t1), TB1 = TAPW(t2, t3, t2, t1), TC1 = TAPW(t0, 0, 0, 0);
+    const uint32_t TA2 = TAPW(0, 0, 0, t0), TB2 = TAPW(t1, t2, t3, t2), TC2 = TAPW(t1, t0, 0, 0);
+    const uint32_t TB3 = TAPW(t0, t1, t2, t3), TC3 = TAPW(t2, t1, t0, 0);
+#undef TAPW
     // pixels of this dword inside the ROI columns [16, 16 + w)
     const int px0 = dwx * 4;
     uint32_t colmask = 0;
@@ -735,15 +740,13 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
                 const uint32_t a = ra[k], b = rb[k], c = rc[k];
                 const int slot = i % 7;
                 ctr[slot] = b;
-                // bytes of (a, b, c) are columns px0-4 .. px0+7; pixel j needs byte offsets j+1 .. j+7
-                const uint32_t w1 = __builtin_amdgcn_alignbyte(b, a, 1), w2 = __builtin_amdgcn_alignbyte(b, a, 2);
-                const uint32_t w3 = __builtin_amdgcn_alignbyte(b, a, 3);
-                const uint32_t w5 = __builtin_amdgcn_alignbyte(c, b, 1), w6 = __builtin_amdgcn_alignbyte(c, b, 2);
-                const uint32_t w7 = __builtin_amdgcn_alignbyte(c, b, 3);
-                h[slot][0] = __builtin_amdgcn_udot4(w1, tapsA, __builtin_amdgcn_udot4(w5, tapsB, 0u, false), false);
-                h[slot][1] = __builtin_amdgcn_udot4(w2, tapsA, __builtin_amdgcn_udot4(w6, tapsB, 0u, false), false);
-                h[slot][2] = __builtin_amdgcn_udot4(w3, tapsA, __builtin_amdgcn_udot4(w7, tapsB, 0u, false), false);
-                h[slot][3] = __builtin_amdgcn_udot4(b, tapsA, __builtin_amdgcn_udot4(c, tapsB, 0u, false), false);
+                // bytes of (a, b, c) are columns px0-4 .. px0+7; pixel j needs byte offsets j+1 .. j+7.  The dwords
+                // stay as loaded and the taps are placed where each pixel's window falls in them (zeros
+                // elsewhere): ten dot products per four pixels and no byte alignment
+                h[slot][0] = __builtin_amdgcn_udot4(a, TA0, __builtin_amdgcn_udot4(b, TB0, 0u, false), false);
+                h[slot][1] = __builtin_amdgcn_udot4(a, TA1, __builtin_amdgcn_udot4(b, TB1, __builtin_amdgcn_udot4(c, TC1, 0u, false), false), false);
+                h[slot][2] = __builtin_amdgcn_udot4(a, TA2, __builtin_amdgcn_udot4(b, TB2, __builtin_amdgcn_udot4(c, TC2, 0u, false), false), false);
+                h[slot][3] = __builtin_amdgcn_udot4(b, TB3, __builtin_amdgcn_udot4(c, TC3, 0u, false), false);
                 if (i >= 6) {
                     const int y = y0 + i - 6;
                     if (y < ph) {
