@@ -135,7 +135,22 @@ void* orbhip_matcher_stream(orbhip_matcher* m);
 int orbhip_knn2_device(orbhip_matcher* m, const uint8_t* d_q, int nq, ptrdiff_t q_pair_stride,
                        const uint8_t* d_t, int nt, ptrdiff_t t_pair_stride, int npairs, int idx_base,
                        int32_t* d_idx, int32_t* d_d1, int32_t* d_d2);
-/* Host-pointer convenience form of the above (copies in and out; blocking). */
+/* No counterpart in the reference.  The same scan as orbhip_knn2_device, same arguments, results and
+ * asynchrony, for callers that cannot allocate device memory while they call: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  The partial results that the train
+ * chunks of one call exchange live in a fixed array in device memory (orbhip_knn2_scratch_bytes()
+ * = 16 MiB per GPU, held until the process ends) instead of the handle's growable workspace; this
+ * call makes no hipMalloc / hipFree.  A call whose partial results (npairs * chunks * nq * 8 bytes,
+ * chunks <= max(1, 8 * CUs / (npairs * ceil(nq / 256)))) exceed the array returns ORBHIP_ECAP and
+ * launches nothing.  All matchers of a GPU share that GPU's array: calls that overlap in time on one
+ * GPU race (calls on one handle are ordered by its stream; handles are not ordered against each
+ * other).  Nothing in the array needs clearing between calls: every entry a call reads it has
+ * written first. */
+int orbhip_knn2_device_noalloc(orbhip_matcher* m, const uint8_t* d_q, int nq, ptrdiff_t q_pair_stride,
+                               const uint8_t* d_t, int nt, ptrdiff_t t_pair_stride, int npairs, int idx_base,
+                               int32_t* d_idx, int32_t* d_d1, int32_t* d_d2);
+int orbhip_knn2_scratch_bytes(void);
+/* Host-pointer convenience form of orbhip_knn2_device (copies in and out; blocking). */
 int orbhip_knn2(orbhip_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int nt, int npairs,
                 int32_t* idx, int32_t* d1, int32_t* d2);
 /* Merge of per-shard results of index-contiguous train shards (shard g owns a contiguous index

@@ -84,6 +84,8 @@ def lib():
     L.orbhip_matcher_stream.argtypes = [vp]
     L.orbhip_matcher_stream.restype = vp
     L.orbhip_knn2_device.argtypes = [vp, vp, i32, pd, vp, i32, pd, i32, i32, vp, vp, vp]
+    L.orbhip_knn2_device_noalloc.argtypes = [vp, vp, i32, pd, vp, i32, pd, i32, i32, vp, vp, vp]
+    L.orbhip_knn2_scratch_bytes.argtypes = []
     L.orbhip_knn2.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp, vp]
     L.orbhip_knn2_merge_device.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     L.orbhip_ratio_test_device.argtypes = [vp, vp, vp, i32, f32, i32, i32, vp]

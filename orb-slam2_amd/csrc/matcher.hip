@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <climits>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../../include/orbhip.h"
@@ -202,6 +203,32 @@ __global__ __launch_bounds__(256) void k_valu_rate(uint32_t* out, int iters, int
 
 }  // namespace
 
+// Partial results of the chunked scan for the entry point that allocates nothing.  Every GPU the
+// library runs on holds its own copy of this array at its own address until the process ends; host
+// code reaches it only through the address hipGetSymbolAddress returns for the current device
+// (the array's name is a host-side stand-in, not a device address).
+#define KNN_SCRATCH_BYTES (16u << 20)
+static __device__ __align__(256) unsigned char scratch[KNN_SCRATCH_BYTES];
+#define KNN_SCRATCH_MAX_DEVICES 64
+static void* g_scratch_ptr[KNN_SCRATCH_MAX_DEVICES];
+static std::mutex g_scratch_mutex;
+
+// Resolves, once per device and with that device current, the address of the device's scratch array.
+static int scratch_for_current_device(int device, void** out) {
+    *out = nullptr;
+    if (device < 0 || device >= KNN_SCRATCH_MAX_DEVICES) return orb_fail(ORBHIP_EINVAL, "device ordinal %d out of range", device);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* ptr = nullptr;
+        const hipError_t err = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+        if (err != hipSuccess || !ptr)
+            return orb_fail(ORBHIP_EHIP, "hipGetSymbolAddress(scratch) failed: %s", hipGetErrorString(err));
+        g_scratch_ptr[device] = ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return ORBHIP_OK;
+}
+
 extern "C" {
 
 int orbhip_device_count(void) {
@@ -226,6 +253,13 @@ int orbhip_matcher_create(orbhip_matcher** out, int device) {
         hipMemset(m->d_err, 0, sizeof(int)) != hipSuccess) {
         orbhip_matcher_destroy(m);
         return orb_fail(ORBHIP_EHIP, "stream/event creation failed");
+    }
+    {
+        const int rc = scratch_for_current_device(device, &m->d_scratch);
+        if (rc) {
+            orbhip_matcher_destroy(m);
+            return rc;
+        }
     }
     *out = m;
     return ORBHIP_OK;
@@ -265,49 +299,92 @@ int orbhip_matcher_synchronize(orbhip_matcher* m) {
 void* orbhip_matcher_stream(orbhip_matcher* m) { return m ? (void*)m->stream : nullptr; }
 float orbhip_matcher_last_elapsed_ms(orbhip_matcher* m) { return m ? m->last_ms : 0.f; }
 
-int orbhip_knn2_device(orbhip_matcher* m, const uint8_t* d_q, int nq, ptrdiff_t q_pair_stride, const uint8_t* d_t, int nt,
-                       ptrdiff_t t_pair_stride, int npairs, int idx_base, int32_t* d_idx, int32_t* d_d1, int32_t* d_d2) {
+// Launch plan of the scan: query blocks, index-contiguous train chunks (enough workgroups to fill the
+// chip several times over; a chunk never exceeds the key's index field) and the bytes of partial
+// results the chunks exchange (0 with a single chunk).
+struct KnnPlan {
+    int qblocks, nchunks, chunk_rows;
+    size_t part_bytes;
+};
+
+static int knn2_check_and_plan(orbhip_matcher* m, const uint8_t* d_q, int nq, ptrdiff_t q_pair_stride, const uint8_t* d_t,
+                               int nt, ptrdiff_t t_pair_stride, int npairs, const int32_t* d_idx, const int32_t* d_d1,
+                               const int32_t* d_d2, KnnPlan* plan) {
     if (!m) return orb_fail(ORBHIP_EINVAL, "null matcher");
     if (nq < 0 || nt < 0 || npairs < 0) return orb_fail(ORBHIP_EINVAL, "negative size");
+    plan->qblocks = plan->nchunks = plan->chunk_rows = 0;
+    plan->part_bytes = 0;
     if (nq == 0 || npairs == 0) return ORBHIP_OK;
     if (!d_q || !d_idx || !d_d1 || !d_d2 || (nt > 0 && !d_t)) return orb_fail(ORBHIP_EINVAL, "null buffer");
     if (((uintptr_t)d_q & 15) || ((uintptr_t)d_t & 3) || (q_pair_stride & 15) || (t_pair_stride & 3))
         return orb_fail(ORBHIP_EINVAL, "descriptor buffers must be 16-byte (queries) / 4-byte (train) aligned");
     if (npairs > 65535) return orb_fail(ORBHIP_EINVAL, "more than 65535 pairs in one call");
-    HIPCHK(hipSetDevice(m->device));
     const int qblocks = (nq + 255) / 256;
-    // enough workgroups to fill the chip several times over; chunks never exceed the key's index field
     const long long want = 8LL * m->sm_count;
     int nchunks = (int)std::max<long long>(1, std::min<long long>((want + (long long)qblocks * npairs - 1) / ((long long)qblocks * npairs),
                                                                     (nt + 511) / 512));
     int chunk_rows = nt > 0 ? (nt + nchunks - 1) / nchunks : 1;
-    if (chunk_rows > (int)KNN_IDX_MASK) {
-        chunk_rows = KNN_IDX_MASK;
-        nchunks = (nt + chunk_rows - 1) / chunk_rows;
-    }
+    if (chunk_rows > (int)KNN_IDX_MASK) chunk_rows = KNN_IDX_MASK;
     nchunks = nt > 0 ? (nt + chunk_rows - 1) / chunk_rows : 1;
     if (nchunks > 65535) return orb_fail(ORBHIP_EINVAL, "train set too large");
-    if (nchunks > 1) {
-        const size_t need = (size_t)npairs * nchunks * nq * sizeof(uint2);
-        if (need > m->part_bytes) {
-            HIPCHK(hipStreamSynchronize(m->stream));
-            if (m->d_part) hipFree(m->d_part);
-            m->d_part = nullptr;
-            m->part_bytes = 0;
-            if (hipMalloc(&m->d_part, need) != hipSuccess) return orb_fail(ORBHIP_ENOMEM, "hipMalloc of %zu bytes failed", need);
-            m->part_bytes = need;
-        }
-    }
+    plan->qblocks = qblocks;
+    plan->nchunks = nchunks;
+    plan->chunk_rows = chunk_rows;
+    plan->part_bytes = nchunks > 1 ? (size_t)npairs * nchunks * nq * sizeof(uint2) : 0;
+    return ORBHIP_OK;
+}
+
+static int knn2_launch(orbhip_matcher* m, const KnnPlan& plan, const uint8_t* d_q, int nq, ptrdiff_t q_pair_stride,
+                       const uint8_t* d_t, int nt, ptrdiff_t t_pair_stride, int npairs, int idx_base, uint2* d_part,
+                       int32_t* d_idx, int32_t* d_d1, int32_t* d_d2) {
     HIPCHK(hipEventRecord(m->ev0, m->stream));
-    hipLaunchKernelGGL(k_knn2, dim3(qblocks, nchunks, npairs), dim3(256), 0, m->stream, (const uint32_t*)d_q, nq,
-                       (long long)(q_pair_stride / 4), (const uint32_t*)d_t, nt, (long long)(t_pair_stride / 4), chunk_rows,
-                       nchunks, idx_base, (uint2*)m->d_part, d_idx, d_d1, d_d2);
-    if (nchunks > 1)
-        hipLaunchKernelGGL(k_knn2_fold, dim3(qblocks, npairs), dim3(256), 0, m->stream, (const uint2*)m->d_part, nq, nchunks,
-                           chunk_rows, idx_base, d_idx, d_d1, d_d2);
+    hipLaunchKernelGGL(k_knn2, dim3(plan.qblocks, plan.nchunks, npairs), dim3(256), 0, m->stream, (const uint32_t*)d_q, nq,
+                       (long long)(q_pair_stride / 4), (const uint32_t*)d_t, nt, (long long)(t_pair_stride / 4),
+                       plan.chunk_rows, plan.nchunks, idx_base, d_part, d_idx, d_d1, d_d2);
+    if (plan.nchunks > 1)
+        hipLaunchKernelGGL(k_knn2_fold, dim3(plan.qblocks, npairs), dim3(256), 0, m->stream, (const uint2*)d_part, nq,
+                           plan.nchunks, plan.chunk_rows, idx_base, d_idx, d_d1, d_d2);
     HIPCHK(hipEventRecord(m->ev1, m->stream));
     HIPCHK(hipGetLastError());
     return ORBHIP_OK;
+}
+
+int orbhip_knn2_device(orbhip_matcher* m, const uint8_t* d_q, int nq, ptrdiff_t q_pair_stride, const uint8_t* d_t, int nt,
+                       ptrdiff_t t_pair_stride, int npairs, int idx_base, int32_t* d_idx, int32_t* d_d1, int32_t* d_d2) {
+    KnnPlan plan;
+    const int rc = knn2_check_and_plan(m, d_q, nq, q_pair_stride, d_t, nt, t_pair_stride, npairs, d_idx, d_d1, d_d2, &plan);
+    if (rc || plan.qblocks == 0) return rc;
+    HIPCHK(hipSetDevice(m->device));
+    if (plan.part_bytes > m->part_bytes) {
+        HIPCHK(hipStreamSynchronize(m->stream));
+        if (m->d_part) hipFree(m->d_part);
+        m->d_part = nullptr;
+        m->part_bytes = 0;
+        if (hipMalloc(&m->d_part, plan.part_bytes) != hipSuccess)
+            return orb_fail(ORBHIP_ENOMEM, "hipMalloc of %zu bytes failed", plan.part_bytes);
+        m->part_bytes = plan.part_bytes;
+    }
+    return knn2_launch(m, plan, d_q, nq, q_pair_stride, d_t, nt, t_pair_stride, npairs, idx_base, (uint2*)m->d_part, d_idx,
+                       d_d1, d_d2);
+}
+
+int orbhip_knn2_scratch_bytes(void) { return (int)KNN_SCRATCH_BYTES; }
+
+int orbhip_knn2_device_noalloc(orbhip_matcher* m, const uint8_t* d_q, int nq, ptrdiff_t q_pair_stride, const uint8_t* d_t,
+                               int nt, ptrdiff_t t_pair_stride, int npairs, int idx_base, int32_t* d_idx, int32_t* d_d1,
+                               int32_t* d_d2) {
+    KnnPlan plan;
+    const int rc = knn2_check_and_plan(m, d_q, nq, q_pair_stride, d_t, nt, t_pair_stride, npairs, d_idx, d_d1, d_d2, &plan);
+    if (rc || plan.qblocks == 0) return rc;
+    if (!m->d_scratch) return orb_fail(ORBHIP_EHIP, "the device's scratch array was not resolved at matcher creation");
+    if (plan.part_bytes > KNN_SCRATCH_BYTES)
+        return orb_fail(ORBHIP_ECAP,
+                        "partial results of this call need %zu bytes, the fixed scratch array holds %u "
+                        "(npairs * chunks * nq * 8 bytes; use orbhip_knn2_device or fewer queries per call)",
+                        plan.part_bytes, (unsigned)KNN_SCRATCH_BYTES);
+    HIPCHK(hipSetDevice(m->device));
+    return knn2_launch(m, plan, d_q, nq, q_pair_stride, d_t, nt, t_pair_stride, npairs, idx_base, (uint2*)m->d_scratch, d_idx,
+                       d_d1, d_d2);
 }
 
 int orbhip_knn2(orbhip_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int nt, int npairs, int32_t* idx, int32_t* d1,

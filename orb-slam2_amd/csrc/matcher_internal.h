@@ -21,6 +21,7 @@ struct orbhip_matcher {
     float last_ms = 0.f;
     void* d_part = nullptr;
     size_t part_bytes = 0;
+    void* d_scratch = nullptr;  // this device's fixed scratch array (not owned; never freed)
     void* d_stage = nullptr;  // staging of the host-pointer entry point
     size_t stage_bytes = 0;
     void* d_work = nullptr;  // workspace of the windowed matchers

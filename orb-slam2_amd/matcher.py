@@ -67,6 +67,12 @@ class ORBmatcher:
         _lib.check(self._L.orbhip_knn2_device(self._h, d_q, nq, q_pair_stride, d_t, nt, t_pair_stride, npairs, idx_base,
                                               d_idx, d_d1, d_d2))
 
+    def knn2_device_noalloc(self, d_q, nq, q_pair_stride, d_t, nt, t_pair_stride, npairs, idx_base, d_idx, d_d1, d_d2):
+        """orbhip_knn2_device_noalloc: the same scan with its partial results in the GPU's fixed scratch
+        array; makes no device allocation."""
+        _lib.check(self._L.orbhip_knn2_device_noalloc(self._h, d_q, nq, q_pair_stride, d_t, nt, t_pair_stride, npairs,
+                                                      idx_base, d_idx, d_d1, d_d2))
+
     def merge_device(self, d_parts, nshards, nq, d_idx, d_d1, d_d2):
         _lib.check(self._L.orbhip_knn2_merge_device(self._h, d_parts, nshards, nq, d_idx, d_d1, d_d2))
 
