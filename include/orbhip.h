@@ -158,6 +158,37 @@ int orbhip_knn2(orbhip_matcher* m, const uint8_t* q, int nq, const uint8_t* t, i
  * Reproduces the serial ascending scan exactly.  Device pointers; asynchronous. */
 int orbhip_knn2_merge_device(orbhip_matcher* m, const int32_t* d_parts, int nshards, int nq,
                              int32_t* d_idx, int32_t* d_d1, int32_t* d_d2);
+/* ---- Frame-versus-map matching over a map sharded across GPUs --------------------------------------
+ * One process per GPU.  The map descriptors are split into index-contiguous shards (rank g owns the
+ * global rows [idx_base_g, idx_base_g + nt_shard_g), rank order = index order); the queries are
+ * replicated.  A communicator wraps one RCCL communicator (ncclComm_t); RCCL is bound at run time
+ * (the copy the process has loaded, else ORBHIP_RCCL_LIB, else librccl.so.1). */
+typedef struct orbhip_comm orbhip_comm;
+#define ORBHIP_COMM_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+/* ncclGetUniqueId: one rank calls it and hands the bytes to every rank by its own means (a file, a
+ * socket, MPI, torch.distributed ...). */
+int orbhip_comm_unique_id(void* id_out, size_t id_bytes);
+/* ncclCommInitRank on `device`: collective over all `world` ranks of the id. */
+int orbhip_comm_create(orbhip_comm** out, const void* id, size_t id_bytes, int rank, int world, int device);
+/* Wraps a communicator the host program already owns (ncclComm_t as void*); it is not destroyed by
+ * orbhip_comm_destroy. */
+int orbhip_comm_adopt(orbhip_comm** out, void* nccl_comm, int rank, int world, int device);
+void orbhip_comm_destroy(orbhip_comm* c);
+int orbhip_comm_rank(const orbhip_comm* c);
+int orbhip_comm_world(const orbhip_comm* c);
+/* Replaces the best / second-best scan of src/ORBmatcher.cc:461-485 over the WHOLE map for nq queries
+ * (the scans Tracking::SearchReferencePointsInFrustum, src/Tracking.cc:880-885, and
+ * LoopClosing::ComputeSim3, src/LoopClosing.cc:263-347, run over their candidate map points, here with
+ * the identity candidate list).  Every rank calls it with the same queries and its own shard; on return
+ * (asynchronously, on the matcher's stream) every rank holds the same d_idx (global row of the first
+ * minimum, or -1 for an empty map), d_d1, d_d2 — bit for bit what one serial ascending scan of the
+ * unsharded map gives.  Steps, all on the matcher's stream: scan of the shard, ONE ncclAllGather of
+ * 3 * nq int32 per rank, ordered merge.  comm == NULL stands for a single shard (no collective).
+ * Collective: every rank of the communicator must call it, in the same order relative to other
+ * collectives on that communicator. */
+int orbhip_knn2_sharded(orbhip_matcher* m, orbhip_comm* comm, const uint8_t* d_q, int nq, const uint8_t* d_t_shard,
+                        int nt_shard, int idx_base, int32_t* d_idx, int32_t* d_d1, int32_t* d_d2);
+
 /* Acceptance predicates of src/ORBmatcher.cc evaluated per query on the device:
  * form 0: (float)d1 < ratio*(float)d2 (:237,:665,:804), 1: d1 <= d2*ratio (:487,:596);
  * accepted iff the ratio form holds and d1 <= th (TH_LOW 20 / TH_HIGH 100, :42-45).

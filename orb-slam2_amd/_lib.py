@@ -37,6 +37,10 @@ def _preload_torch_hip_runtime():
             C.CDLL(cand, mode=C.RTLD_GLOBAL)
         except OSError:
             pass
+    # the copy of RCCL torch would load: named here so that liborbhip.so binds to the same one
+    rccl = os.path.join(os.path.dirname(spec.origin), "lib", "librccl.so")
+    if os.path.exists(rccl):
+        os.environ.setdefault("ORBHIP_RCCL_LIB", rccl)
 
 
 class OrbCamera(C.Structure):
@@ -88,6 +92,14 @@ def lib():
     L.orbhip_knn2_scratch_bytes.argtypes = []
     L.orbhip_knn2.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp, vp]
     L.orbhip_knn2_merge_device.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+    L.orbhip_comm_unique_id.argtypes = [vp, sz]
+    L.orbhip_comm_create.argtypes = [C.POINTER(vp), vp, sz, i32, i32, i32]
+    L.orbhip_comm_adopt.argtypes = [C.POINTER(vp), vp, i32, i32, i32]
+    L.orbhip_comm_destroy.argtypes = [vp]
+    L.orbhip_comm_destroy.restype = None
+    L.orbhip_comm_rank.argtypes = [vp]
+    L.orbhip_comm_world.argtypes = [vp]
+    L.orbhip_knn2_sharded.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp, vp, vp]
     L.orbhip_ratio_test_device.argtypes = [vp, vp, vp, i32, f32, i32, i32, vp]
     L.orbhip_matcher_last_elapsed_ms.argtypes = [vp]
     L.orbhip_matcher_last_elapsed_ms.restype = f32

@@ -22,6 +22,8 @@ struct orbhip_matcher {
     void* d_part = nullptr;
     size_t part_bytes = 0;
     void* d_scratch = nullptr;  // this device's fixed scratch array (not owned; never freed)
+    void* d_gather = nullptr;  // receive buffer of the map-sharded scan's all-gather
+    size_t gather_bytes = 0;
     void* d_stage = nullptr;  // staging of the host-pointer entry point
     size_t stage_bytes = 0;
     void* d_work = nullptr;  // workspace of the windowed matchers

@@ -17,6 +17,60 @@ def shard_range(n, rank, world):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+class Communicator:
+    """orbhip_comm: one RCCL communicator (ncclComm_t) created inside liborbhip.so, one rank per process
+    and GPU.  unique_id: the 128 bytes of orbhip_comm_unique_id() of ONE rank, handed to all ranks."""
+
+    def __init__(self, unique_id, rank, world, device):
+        import ctypes as C
+        from . import _lib
+        self._L = _lib.lib()
+        self._h = C.c_void_p()
+        buf = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
+        _lib.check(self._L.orbhip_comm_create(C.byref(self._h), buf, 128, rank, world, device))
+        self.rank, self.world, self.device = rank, world, device
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+        from . import _lib
+        buf = (C.c_ubyte * 128)()
+        _lib.check(_lib.lib().orbhip_comm_unique_id(buf, 128))
+        return bytes(buf)
+
+    @classmethod
+    def from_torch_distributed(cls, dist, device, group=None):
+        """The id travels through the process group that already exists (any backend); the communicator
+        itself is liborbhip.so's own."""
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return cls(box[0], rank, world, device)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.orbhip_comm_destroy(self._h)
+            self._h.value = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def knn2_sharded_rccl(matcher, comm, d_q, nq, d_t_shard, nt_shard, idx_base, out):
+    """orbhip_knn2_sharded: scan of this rank's shard, one RCCL all-gather and the ordered merge, all
+    queued on the matcher's stream by the library (no torch collective, no host synchronisation).
+    comm: Communicator or None (single shard).  out: int32 CUDA tensor [3, nq] (idx, d1, d2), identical
+    on every rank after matcher.synchronize()."""
+    from . import _lib
+    _lib.check(matcher._L.orbhip_knn2_sharded(matcher._h, None if comm is None else comm._h, d_q.data_ptr(), nq,
+                                              d_t_shard.data_ptr(), nt_shard, idx_base, out[0].data_ptr(),
+                                              out[1].data_ptr(), out[2].data_ptr()))
+    return out
+
+
 def knn2_sharded(matcher, d_q, nq, d_t_shard, nt_shard, idx_base, parts_local, parts_all, out, dist=None, group=None):
     """Frame-vs-map kNN on one rank.
 
