@@ -23,80 +23,7 @@
 
 namespace {
 
-#define KNN_IDX_BITS 22
-#define KNN_IDX_MASK ((1u << KNN_IDX_BITS) - 1u)
-#define KNN_NONE 0xffffffffu
-
-// popcount(x) + acc in one instruction; the explicit form keeps the 8-word distance a chain of
-// 8 v_xor_b32 + 8 v_bcnt_u32_b32 (the compiler otherwise splits the sum into a tree with extra adds)
-__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
-    uint32_t r;
-    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
-    return r;
-}
-__device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c) {
-    uint32_t r;
-    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
-__device__ __forceinline__ uint32_t ham8(const uint32_t q[8], const uint32_t* __restrict__ t) {
-    uint32_t d = bcnt_acc(q[0] ^ t[0], 0u);
-    d = bcnt_acc(q[1] ^ t[1], d);
-    d = bcnt_acc(q[2] ^ t[2], d);
-    d = bcnt_acc(q[3] ^ t[3], d);
-    d = bcnt_acc(q[4] ^ t[4], d);
-    d = bcnt_acc(q[5] ^ t[5], d);
-    d = bcnt_acc(q[6] ^ t[6], d);
-    d = bcnt_acc(q[7] ^ t[7], d);
-    return d;
-}
-
-// Folds one candidate key into the running two smallest keys (best <= best2 always holds, so the
-// new second smallest is the median of the three).
-__device__ __forceinline__ void fold_key(uint32_t key, uint32_t& best, uint32_t& best2) {
-    best2 = med3_u32(best, key, best2);
-    best = min(best, key);
-}
-
-// grid: (query blocks of 256, train chunks, pairs).  Each block scans rows [chunk*chunk_rows,
-// min(nt, (chunk+1)*chunk_rows)) and emits its two smallest keys per query.  With one chunk the
-// final (idx, d1, d2) are written directly.
-__global__ __launch_bounds__(256) void k_knn2(const uint32_t* __restrict__ q, int nq, long long q_pair_words,
-                                              const uint32_t* __restrict__ t, int nt, long long t_pair_words,
-                                              int chunk_rows, int nchunks, int idx_base, uint2* __restrict__ part,
-                                              int32_t* __restrict__ o_idx, int32_t* __restrict__ o_d1,
-                                              int32_t* __restrict__ o_d2) {
-    const int pair = blockIdx.z, chunk = blockIdx.y;
-    const int qi = blockIdx.x * 256 + threadIdx.x;
-    uint32_t qw[8];
-    {
-        const uint32_t* qp = q + (long long)pair * q_pair_words + (long long)min(qi, nq - 1) * 8;
-        const uint4 a = *(const uint4*)qp, b = *(const uint4*)(qp + 4);
-        qw[0] = a.x; qw[1] = a.y; qw[2] = a.z; qw[3] = a.w;
-        qw[4] = b.x; qw[5] = b.y; qw[6] = b.z; qw[7] = b.w;
-    }
-    const int j0 = chunk * chunk_rows;
-    const int rows = min(nt - j0, chunk_rows);
-    const uint32_t* __restrict__ tp = t + (long long)pair * t_pair_words + (long long)j0 * 8;
-    uint32_t best = KNN_NONE, best2 = KNN_NONE;
-    int j = 0;
-    for (; j + 8 <= rows; j += 8) {
-#pragma unroll
-        for (int u = 0; u < 8; u++)
-            fold_key((ham8(qw, tp + (long long)(j + u) * 8) << KNN_IDX_BITS) | (uint32_t)(j + u), best, best2);
-    }
-    for (; j < rows; j++) fold_key((ham8(qw, tp + (long long)j * 8) << KNN_IDX_BITS) | (uint32_t)j, best, best2);
-    if (qi >= nq) return;
-    if (nchunks == 1) {
-        const long long o = (long long)pair * nq + qi;
-        o_idx[o] = best == KNN_NONE ? -1 : (int)(best & KNN_IDX_MASK) + idx_base;
-        o_d1[o] = best == KNN_NONE ? INT_MAX : (int)(best >> KNN_IDX_BITS);
-        o_d2[o] = best2 == KNN_NONE ? INT_MAX : (int)(best2 >> KNN_IDX_BITS);
-    } else {
-        part[((long long)pair * nchunks + chunk) * nq + qi] = make_uint2(best, best2);
-    }
-}
+#include "knn2_kernel.h"
 
 // Chunks are index-contiguous and visited in ascending order, so folding each chunk's two
 // smallest distances with the reference's update rule reproduces the serial scan.
@@ -321,9 +248,12 @@ static int knn2_check_and_plan(orbhip_matcher* m, const uint8_t* d_q, int nq, pt
         return orb_fail(ORBHIP_EINVAL, "descriptor buffers must be 16-byte (queries) / 4-byte (train) aligned");
     if (npairs > 65535) return orb_fail(ORBHIP_EINVAL, "more than 65535 pairs in one call");
     const int qblocks = (nq + 255) / 256;
-    const long long want = 8LL * m->sm_count;
-    int nchunks = (int)std::max<long long>(1, std::min<long long>((want + (long long)qblocks * npairs - 1) / ((long long)qblocks * npairs),
-                                                                    (nt + 511) / 512));
+    // Few (query block, pair) units: cut the train set into chunks so that the grid fills the chip KNN_BLOCKS_PER_CU
+    // workgroups deep (every chunk the same number of rows).  A chunk keeps >= 2048 rows, so the unconditional
+    // folds of its first rows stay a small share.  Many units: one chunk each.
+    const long long units = (long long)qblocks * npairs;
+    const long long resident = (long long)KNN_BLOCKS_PER_CU * m->sm_count;
+    int nchunks = (int)std::max<long long>(1, std::min<long long>(resident / units, (nt + 2047) / 2048));
     int chunk_rows = nt > 0 ? (nt + nchunks - 1) / nchunks : 1;
     if (chunk_rows > (int)KNN_IDX_MASK) chunk_rows = KNN_IDX_MASK;
     nchunks = nt > 0 ? (nt + chunk_rows - 1) / chunk_rows : 1;

@@ -20,6 +20,43 @@ def test_knn2_single_pair(orb, orbref, synth, nq, nt):
     assert np.array_equal(d2, rd2)
 
 
+@pytest.mark.parametrize("nt", [8, 9, 15, 16, 511, 512, 513, 519, 520, 527, 1031, 4099])
+def test_knn2_group_boundaries(orb, orbref, synth, nt):
+    """Train sizes around the scan's internal boundaries: groups of 8 rows, the 512 rows folded unconditionally
+    before the threshold filter starts, and the rows left over after the last whole group."""
+    q, t = synth.synth_descriptors(300, nt, seed=4242 + nt)
+    # the best rows of some queries sit at the very end and right after the unconditional part
+    q[0] = t[nt - 1]
+    q[1] = t[nt - 1] ^ np.uint8(1)
+    if nt > 513:
+        q[2] = t[512]
+        t[513] = t[512]
+        q[3] = t[nt - 2]
+        t[nt - 1] = t[nt - 2]
+    m = orb.ORBmatcher(0.6, True)
+    idx, d1, d2 = m.knn2(q, t)
+    ridx, rd1, rd2 = orbref.knn2(q, t)
+    assert np.array_equal(idx, ridx) and np.array_equal(d1, rd1) and np.array_equal(d2, rd2)
+
+
+def test_knn2_late_improvements(orb, orbref):
+    """Distances that keep falling along the scan (row j differs from the query in about 200 - j/20 bits), so the
+    filtered steady state takes its exact-fold path again and again, with equal distances in neighbouring rows."""
+    rng = np.random.default_rng(77)
+    nq, nt = 130, 3000
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    base = q[rng.integers(0, nq, nt)]
+    bits = np.zeros((nt, 256), np.uint8)
+    for j in range(nt):
+        k = max(0, 200 - j // 20)
+        bits[j, rng.permutation(256)[:k]] = 1
+    t = base ^ np.packbits(bits, axis=1)
+    m = orb.ORBmatcher(0.6, True)
+    idx, d1, d2 = m.knn2(q, t)
+    ridx, rd1, rd2 = orbref.knn2(q, t)
+    assert np.array_equal(idx, ridx) and np.array_equal(d1, rd1) and np.array_equal(d2, rd2)
+
+
 def test_knn2_empty_train(orb):
     m = orb.ORBmatcher()
     q = np.zeros((5, 32), np.uint8)
