@@ -49,6 +49,28 @@ struct DeviceBuf {
     template <class T> T* as() const { return (T*)p; }
 };
 
+// Page-locked host staging of the host-pointer entry points (grown on demand, kept in the handle).
+struct PinnedBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return ORBHIP_OK;
+        if (p) hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+        if (hipHostMalloc(&p, need, hipHostMallocDefault) != hipSuccess)
+            return orb_fail(ORBHIP_ENOMEM, "hipHostMalloc of %zu bytes failed", need);
+        bytes = need;
+        return ORBHIP_OK;
+    }
+    void release() {
+        if (p) hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T> T* as() const { return (T*)p; }
+};
+
 }  // namespace
 
 struct orbhip_extractor {
@@ -87,7 +109,10 @@ struct orbhip_extractor {
 
     DeviceBuf d_geom, d_cells, d_xofs, d_xab, d_ysrc, d_yab, d_disc, d_pattern;
     DeviceBuf d_pyr, d_blur, d_score, d_cand, d_cand64, d_ntotal, d_nretain, d_lvl, d_lvlcount, d_angles, d_slots, d_err;
-    DeviceBuf d_img, d_kp, d_desc, d_n;  // staging of the host-pointer entry points
+    // staging of the host-pointer entry points: frames in, one output block (counts, keypoints, descriptors)
+    // on the device and page-locked mirrors of both, so that a call is two copies and one synchronisation
+    DeviceBuf d_img, d_outblk;
+    PinnedBuf h_img, h_outblk;
 };
 
 namespace {
@@ -295,6 +320,8 @@ int set_size(orbhip_extractor* e, int rows, int cols, int batch) {
         int mch = 0;
         int rc = build_geometry(e, rows, cols, g, cells, xofs, xab, ysrc, yab, mch);
         if (rc) return rc;
+        // a rebuild that fails half way must not leave the handle claiming the old size: force a full rebuild next time
+        e->cur_rows = e->cur_cols = 0;
         if ((rc = upload(e->d_geom, &g, sizeof(g), e->stream))) return rc;
         if ((rc = upload(e->d_cells, cells.data(), cells.size() * sizeof(CellDesc), e->stream))) return rc;
         if ((rc = upload(e->d_xofs, xofs.data(), xofs.size() * sizeof(int), e->stream))) return rc;
@@ -508,8 +535,10 @@ void orbhip_extractor_destroy(orbhip_extractor* e) {
     if (e->stream) hipStreamSynchronize(e->stream);
     DeviceBuf* bufs[] = {&e->d_geom, &e->d_cells, &e->d_xofs, &e->d_xab, &e->d_ysrc, &e->d_yab, &e->d_disc, &e->d_pattern,
                          &e->d_pyr, &e->d_blur, &e->d_score, &e->d_cand, &e->d_cand64, &e->d_ntotal, &e->d_nretain, &e->d_lvl,
-                         &e->d_lvlcount, &e->d_angles, &e->d_slots, &e->d_err, &e->d_img, &e->d_kp, &e->d_desc, &e->d_n};
+                         &e->d_lvlcount, &e->d_angles, &e->d_slots, &e->d_err, &e->d_img, &e->d_outblk};
     for (DeviceBuf* b : bufs) b->release();
+    e->h_img.release();
+    e->h_outblk.release();
     for (hipEvent_t ev : e->prof_ev) hipEventDestroy(ev);
     for (hipEvent_t ev : e->worker_done) hipEventDestroy(ev);
     for (hipStream_t st : e->workers) hipStreamDestroy(st);
@@ -577,7 +606,8 @@ int orbhip_extract_batch_device(orbhip_extractor* e, const uint8_t* d_imgs, int 
     return ORBHIP_OK;
 }
 
-int orbhip_extractor_synchronize(orbhip_extractor* e) {
+// Waits for the handle's stream and reads the event timings of the last call.
+static int wait_and_collect_times(orbhip_extractor* e) {
     if (!e) return orb_fail(ORBHIP_EINVAL, "null extractor");
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -599,7 +629,12 @@ int orbhip_extractor_synchronize(orbhip_extractor* e) {
                 if (hipEventElapsedTime(&ms, pev[s], pev[s + 1]) == hipSuccess) e->stage_ms[s] += ms;
             }
     }
-    return check_device_error(e);
+    return ORBHIP_OK;
+}
+
+int orbhip_extractor_synchronize(orbhip_extractor* e) {
+    const int rc = wait_and_collect_times(e);
+    return rc ? rc : check_device_error(e);
 }
 
 int orbhip_extractor_set_profiling(orbhip_extractor* e, int enable) {
@@ -630,31 +665,51 @@ int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int batch, in
     HIPCHK(hipSetDevice(e->device));
     const int chunk = std::min(batch, e->max_batch);
     const size_t img_bytes = (size_t)rows * cols;
+    // output block of a chunk: [device error flags, 16 B][counts][keypoints][descriptors], each part 256-byte aligned
+    const size_t n_off = 256, kp_off = n_off + (((size_t)chunk * sizeof(int) + 255) & ~(size_t)255);
+    const size_t desc_off = kp_off + ((sizeof(OrbKeypoint) * (size_t)cap * chunk + 255) & ~(size_t)255);
+    const size_t blk_bytes = desc_off + (size_t)32 * cap * chunk;
     if ((rc = e->d_img.ensure(img_bytes * chunk))) return rc;
-    if ((rc = e->d_kp.ensure(sizeof(OrbKeypoint) * (size_t)cap * chunk))) return rc;
-    if ((rc = e->d_desc.ensure((size_t)32 * cap * chunk))) return rc;
-    if ((rc = e->d_n.ensure(sizeof(int) * (size_t)chunk))) return rc;
+    if ((rc = e->d_outblk.ensure(blk_bytes))) return rc;
+    if ((rc = e->h_img.ensure(img_bytes * chunk))) return rc;
+    if ((rc = e->h_outblk.ensure(blk_bytes))) return rc;
+    uint8_t* const dblk = e->d_outblk.as<uint8_t>();
+    const uint8_t* const hblk = e->h_outblk.as<uint8_t>();
     for (int f0 = 0; f0 < batch; f0 += chunk) {
         const int b = std::min(chunk, batch - f0);
-        for (int f = 0; f < b; f++)
-            HIPCHK(hipMemcpy2DAsync(e->d_img.as<uint8_t>() + (size_t)f * img_bytes, cols,
-                                    imgs + (ptrdiff_t)(f0 + f) * frame_stride, row_stride, cols, rows,
-                                    hipMemcpyHostToDevice, e->stream));
-        rc = orbhip_extract_batch_device(e, e->d_img.as<uint8_t>(), b, rows, cols, cols, (ptrdiff_t)img_bytes,
-                                         e->d_kp.as<OrbKeypoint>(), e->d_desc.as<uint8_t>(), cap, e->d_n.as<int>());
-        if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(n_out + f0, e->d_n.p, sizeof(int) * b, hipMemcpyDeviceToHost, e->stream));
-        if ((rc = orbhip_extractor_synchronize(e))) return rc;
+        // frames -> page-locked staging (packed rows), one host-to-device copy
+        uint8_t* hin = e->h_img.as<uint8_t>();
         for (int f = 0; f < b; f++) {
-            const int n = n_out[f0 + f];
-            if (n > 0) {
-                HIPCHK(hipMemcpyAsync(kp_out + (size_t)(f0 + f) * cap, e->d_kp.as<OrbKeypoint>() + (size_t)f * cap,
-                                      sizeof(OrbKeypoint) * n, hipMemcpyDeviceToHost, e->stream));
-                HIPCHK(hipMemcpyAsync(desc_out + (size_t)(f0 + f) * cap * 32, e->d_desc.as<uint8_t>() + (size_t)f * cap * 32,
-                                      (size_t)32 * n, hipMemcpyDeviceToHost, e->stream));
+            const uint8_t* src = imgs + (ptrdiff_t)(f0 + f) * frame_stride;
+            if (row_stride == cols) {
+                memcpy(hin + (size_t)f * img_bytes, src, img_bytes);
+            } else {
+                for (int r = 0; r < rows; r++) memcpy(hin + (size_t)f * img_bytes + (size_t)r * cols, src + (ptrdiff_t)r * row_stride, cols);
             }
         }
-        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(hipMemcpyAsync(e->d_img.p, hin, img_bytes * b, hipMemcpyHostToDevice, e->stream));
+        rc = orbhip_extract_batch_device(e, e->d_img.as<uint8_t>(), b, rows, cols, cols, (ptrdiff_t)img_bytes,
+                                         (OrbKeypoint*)(dblk + kp_off), dblk + desc_off, cap, (int*)(dblk + n_off));
+        if (rc) return rc;
+        // error flags and the whole output block come back with ONE synchronisation; the counts say how much of it is valid
+        HIPCHK(hipMemcpyAsync(dblk, e->d_err.p, sizeof(int), hipMemcpyDeviceToDevice, e->stream));
+        const size_t used = desc_off + (size_t)32 * cap * b;
+        HIPCHK(hipMemcpyAsync((void*)hblk, dblk, used, hipMemcpyDeviceToHost, e->stream));
+        if ((rc = wait_and_collect_times(e))) return rc;
+        const int herr = *(const int*)hblk;
+        if (herr) {
+            hipMemset(e->d_err.p, 0, sizeof(int));
+            return orb_fail(ORBHIP_ECAP, "device arena overflow (flags %d)", herr);
+        }
+        const int* hn = (const int*)(hblk + n_off);
+        for (int f = 0; f < b; f++) {
+            const int n = hn[f];
+            n_out[f0 + f] = n;
+            if (n > 0) {
+                memcpy(kp_out + (size_t)(f0 + f) * cap, hblk + kp_off + sizeof(OrbKeypoint) * (size_t)f * cap, sizeof(OrbKeypoint) * n);
+                memcpy(desc_out + (size_t)(f0 + f) * cap * 32, hblk + desc_off + (size_t)32 * f * cap, (size_t)32 * n);
+            }
+        }
     }
     return ORBHIP_OK;
 }

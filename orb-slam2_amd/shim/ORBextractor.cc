@@ -42,22 +42,28 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray, std::vector
         if (rc != ORBHIP_OK) throw std::runtime_error(std::string("orbhip_extractor_create: ") + orbhip_last_error());
     }
     static_assert(sizeof(cv::KeyPoint) == sizeof(OrbKeypoint), "cv::KeyPoint must be the 28-byte 2.4 layout");
-    std::vector<OrbKeypoint> kps(nfeatures);
-    std::vector<unsigned char> desc((size_t)nfeatures * 32);
+    // Keypoints land directly in the caller's vector (cv::KeyPoint and OrbKeypoint are the same 28 bytes);
+    // descriptors go through a member buffer that is sized once.
+    if (descbuf.size() < (size_t)nfeatures * 32) descbuf.resize((size_t)nfeatures * 32);
+    _keypoints.resize(nfeatures);
     int n = 0;
-    int rc = orbhip_extract(handle, image.ptr<unsigned char>(), image.rows, image.cols, (ptrdiff_t)image.step, kps.data(),
-                            desc.data(), nfeatures, &n);
-    if (rc != ORBHIP_OK) throw std::runtime_error(std::string("orbhip_extract: ") + orbhip_last_error());
+    int rc = orbhip_extract(handle, image.ptr<unsigned char>(), image.rows, image.cols, (ptrdiff_t)image.step,
+                            (OrbKeypoint*)(void*)&_keypoints[0], &descbuf[0], nfeatures, &n);
+    if (rc != ORBHIP_OK) {
+        _keypoints.clear();
+        throw std::runtime_error(std::string("orbhip_extract: ") + orbhip_last_error());
+    }
+    _keypoints.resize(n);
     if (n == 0)
         _descriptors.release();
     else {
         _descriptors.create(n, 32, CV_8U);
         cv::Mat d = _descriptors.getMat();
-        for (int i = 0; i < n; i++) memcpy(d.ptr<unsigned char>(i), &desc[(size_t)i * 32], 32);
+        if (d.isContinuous())
+            memcpy(d.ptr<unsigned char>(0), &descbuf[0], (size_t)n * 32);
+        else
+            for (int i = 0; i < n; i++) memcpy(d.ptr<unsigned char>(i), &descbuf[(size_t)i * 32], 32);
     }
-    _keypoints.clear();
-    _keypoints.resize(n);
-    if (n) memcpy((void*)&_keypoints[0], kps.data(), sizeof(OrbKeypoint) * (size_t)n);
 }
 
 }  // namespace ORB_SLAM

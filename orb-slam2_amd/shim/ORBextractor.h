@@ -46,7 +46,7 @@ protected:
 
     orbhip_extractor* handle;  // created at the first call, when the image size is known
     int device;
-    std::vector<unsigned char> kpbuf;
+    std::vector<unsigned char> descbuf;  // descriptor staging, sized at the first call
 
 private:
     ORBextractor(const ORBextractor&);

@@ -46,6 +46,7 @@ public:
         step = 0;
     }
     bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
+    bool isContinuous() const { return step == (size_t)cols; }
     int type() const { return CV_8UC1; }
     template <class T> T* ptr(int r = 0) { return (T*)(data + (size_t)r * step); }
     template <class T> const T* ptr(int r = 0) const { return (const T*)(data + (size_t)r * step); }

@@ -3,7 +3,10 @@
 // descriptors as raw binary for the Python test to compare with the oracle.
 //   shim_test <in.raw> <rows> <cols> <nfeatures> <out.bin>
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
+#include <ctime>
+#include <string>
 #include <vector>
 
 #include "ORBextractor.h"
@@ -30,7 +33,36 @@ struct FakeFrame {
 };
 int FakeFrame::mnMinX, FakeFrame::mnMinY, FakeFrame::mnMaxX, FakeFrame::mnMaxY;
 
+// shim_test --latency <in.raw> <rows> <cols> <nfeatures> <calls>: the call of src/Frame.cc:61 repeated on one
+// image, one frame per call as the tracking thread makes it; prints the median, 10th and 90th percentile of the
+// wall-clock time per call in microseconds and the keypoint count (after 20 warm-up calls).
+static int latency_mode(int argc, char** argv) {
+    if (argc < 7) return 2;
+    const int rows = atoi(argv[3]), cols = atoi(argv[4]), nf = atoi(argv[5]), calls = atoi(argv[6]);
+    std::vector<unsigned char> buf((size_t)rows * cols);
+    FILE* f = fopen(argv[2], "rb");
+    if (!f || fread(buf.data(), 1, buf.size(), f) != buf.size()) return 3;
+    fclose(f);
+    cv::Mat im(rows, cols, CV_8U, buf.data(), (size_t)cols);
+    ORB_SLAM::ORBextractor extractor(nf, 1.2f, 8, ORB_SLAM::ORBextractor::FAST_SCORE, 20);
+    std::vector<cv::KeyPoint> keys;
+    cv::Mat descriptors;
+    std::vector<double> us;
+    for (int i = 0; i < calls + 20; i++) {
+        timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        extractor(im, cv::Mat(), keys, descriptors);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if (i >= 20) us.push_back((t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3);
+    }
+    std::sort(us.begin(), us.end());
+    printf("{\"calls\": %d, \"median_us\": %.1f, \"p10_us\": %.1f, \"p90_us\": %.1f, \"keypoints\": %d}\n", calls,
+           us[us.size() / 2], us[us.size() / 10], us[us.size() * 9 / 10], (int)keys.size());
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "--latency") return latency_mode(argc, argv);
     if (argc < 6) return 2;
     const int rows = atoi(argv[2]), cols = atoi(argv[3]), nf = atoi(argv[4]);
     std::vector<unsigned char> buf((size_t)rows * cols);
