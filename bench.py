@@ -5,25 +5,34 @@
 
 One "step" is one pass of the extractor (pyramid, cell-grid FAST, selection, orientation, blur,
 rotated-BRIEF descriptors, keypoint records) over one batch of synthetic frames that is already
-resident in HBM.  The workload is the 1-GPU configuration of the headline metric: a batch of 256
-synthetic 1280x720 frames, 2000 features per frame.  With N > 1 (one process per GPU, launched by
-torch.distributed.run) every rank processes its own batch of 256 frames: frames are independent,
-so the path is sharded by frame batch with no data-path collective (weak scaling); the only
-collectives are the timing barrier and a MAX over ranks of the elapsed time.
+resident in HBM.  The workload is the configuration the headline metric is quoted on: 640x480 frames,
+1000 features per frame (8 levels, scale 1.2), 256 frames per GPU and step.  With N > 1 (one process
+per GPU, launched by torch.distributed.run) every rank processes its own batch of 256 frames: frames
+are independent, so the path is sharded by frame batch with no data-path collective (weak scaling);
+the only collectives of the timed region are the timing barrier and a MAX over ranks of the elapsed time.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      the dominant kernel group against HBM bandwidth (durations from HIP events on the
                 library's stream, collected in a separate profiled pass after the timed region)
   cpu_baseline  the CPU oracle (oracle/, a port of the reference's CPU path) timed on the host
-                cores of this box on a bounded sample of the same frames
-  extra         the 640x480 / 1000-feature extraction rate and the Hamming kNN rate of the
-                same library, measured after the main timed region.
+                cores of this box on a bounded sample of the same frames: one thread (how the reference
+                runs the path) with the all-core figure beside it
+  extra         N = 1: the 1280x720 / 2000 and 1920x1080 / 4000 extraction legs with their stage
+                rooflines, the Hamming kNN legs (4096 frame pairs; one 1.25 M-row map shard) with the
+                popcount roofline, the rate with host buffers (PCIe inclusive), the latency of one frame
+                per call, the windowed / projection / BoW matcher legs.
+                N > 1: the rank-local legs of the multi-GPU configurations: Hamming kNN of 4096 pairs per
+                rank, the 2048-frame 1920x1080 / 4000 batch split contiguously over the ranks, and 4000
+                queries against a 10 M-row map split into one shard per rank with one RCCL all-gather.
 """
 import argparse
 import importlib
 import json
 import os
+import subprocess
 import sys
+import tempfile
+import threading
 import time
 
 import numpy as np
@@ -32,6 +41,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, spec
+
+KERNEL_OF_STAGE = {"level0": "k_level0", "resize": "k_resize", "fast_measure": "k_score", "select": "k_cell_select",
+                   "orient": "k_orient_describe", "blur": "k_blur", "describe": "k_orient_describe"}
 
 
 def pyramid_pixels(ext, nlevels):
@@ -42,14 +54,25 @@ def make_frames(synth, w, h, n, first):
     return np.stack([synth.synth_image(w, h, first + i) for i in range(n)])
 
 
+def oracle():
+    """The CPU oracle: the checker and the CPU baseline, never part of the measured GPU path."""
+    p = os.path.join(ROOT, "oracle")
+    if p not in sys.path:
+        sys.path.insert(0, p)
+    import orbref
+    orbref.lib()
+    return orbref
+
+
 class ExtractWorkload:
     """Batch of frames resident in HBM + preallocated device outputs."""
 
-    def __init__(self, orb, torch, dev, w, h, nfeatures, batch, first_idx, frames=None):
+    def __init__(self, orb, torch, dev, w, h, nfeatures, batch, first_idx, frames=None, max_batch=None):
         self.torch = torch
         self.w, self.h, self.nf, self.batch = w, h, nfeatures, batch
         self.host = frames if frames is not None else make_frames(orb.synth, w, h, batch, first_idx)
-        self.ext = orb.ORBextractor(nfeatures, 1.2, 8, 1, 20, device=dev, max_width=w, max_height=h, max_batch=batch)
+        self.ext = orb.ORBextractor(nfeatures, 1.2, 8, 1, 20, device=dev, max_width=w, max_height=h,
+                                    max_batch=max_batch or batch)
         self.d_img = torch.from_numpy(self.host).to("cuda:%d" % dev)
         self.d_kp = torch.zeros((batch, nfeatures, 7), dtype=torch.float32, device="cuda:%d" % dev)
         self.d_desc = torch.zeros((batch, nfeatures, 32), dtype=torch.uint8, device="cuda:%d" % dev)
@@ -63,13 +86,35 @@ class ExtractWorkload:
     def sync(self):
         self.ext.synchronize()
 
+    def timed(self, steps, warmup):
+        for _ in range(warmup):
+            self.step()
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.sync()
+        return time.perf_counter() - t0
 
-def cpu_baseline(frames, nfeatures, threads, sample):
+    def mismatching(self, ref_results):
+        """Frames of this batch whose device output differs from the oracle's (keypoint records and
+        descriptors compared bit for bit)."""
+        kp = self.d_kp.cpu().numpy().view(np.uint32)
+        desc = self.d_desc.cpu().numpy()
+        ncount = self.d_n.cpu().numpy()
+        mism = 0
+        for i, (rkp, rdesc) in enumerate(ref_results):
+            n = len(rkp)
+            same = ncount[i] == n and np.array_equal(kp[i, :n].reshape(-1), rkp.view(np.uint32).reshape(-1)) \
+                and np.array_equal(desc[i, :n], rdesc)
+            mism += 0 if same else 1
+        return mism
+
+
+def cpu_extract(frames, nfeatures, threads, sample):
     """Oracle (CPU port of the reference path) on `threads` host threads over `sample` frames."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import orbref
+    orbref = oracle()
     from concurrent.futures import ThreadPoolExecutor
-    orbref.lib()
     sample = min(sample, len(frames))
     exts = [orbref.RefExtractor(nfeatures, 1.2, 8, 1, 20) for _ in range(threads)]
     results = [None] * sample
@@ -86,23 +131,100 @@ def cpu_baseline(frames, nfeatures, threads, sample):
     return sample / dt, results
 
 
-
-def _pmc_traffic(kernel, args):
-    """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/*pmc_traffic.json,
-    made by tools/pmc_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
-    same workload).  Counters cannot be collected from inside the timed run, so the figure is the one
-    of the latest committed pass; None if there is none or the workload is not the default one."""
-    if (args.batch, args.width, args.height, args.features) != (256, 1280, 720, 2000):
-        return None
+def _pmc_traffic(kernel, wl):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/*pmc_traffic.json, made by
+    tools/pmc_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+    workload).  Counters cannot be collected from inside the timed run, so the figure is the one of the
+    latest committed pass of the same workload; None if there is none."""
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*pmc_traffic.json")))
-    if not files:
-        return None
-    try:
-        k = json.load(open(files[-1]))["kernels"].get(kernel)
-        return k["traffic"] if k else None
-    except (OSError, ValueError, KeyError):
-        return None
+    want = "%dx%dx%d/%d" % (wl.batch, wl.w, wl.h, wl.nf)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
+        try:
+            j = json.load(open(f))
+            if j.get("workload", "256x1280x720/2000") != want:
+                continue
+            k = j["kernels"].get(kernel)
+            return k["traffic"] if k else None
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
+
+
+def extract_roofline(wl, prof_steps):
+    """Stage durations from HIP events on the library's stream (single-stream profiling pass of the
+    library) against the algorithmic bytes of each kernel group: the 5 B/pixel + 60 B/keypoint of the
+    whole path split by who must move them (pyramid: read + write; FAST: read; blur: read + write;
+    outputs: 32 B descriptor + 28 B keypoint)."""
+    nl = wl.ext.GetLevels()
+    P = pyramid_pixels(wl.ext, nl)
+    wl.ext.set_profiling(True)
+    acc = {}
+    for _ in range(prof_steps):
+        wl.step()
+        wl.sync()
+        for s, (ms, n) in wl.ext.stage_times().items():
+            a = acc.setdefault(s, [0.0, 0])
+            a[0] += ms
+            a[1] += n
+    wl.ext.set_profiling(False)
+    N_frame = int(wl.d_n.sum().item()) / wl.batch
+    lvl0 = wl.w * wl.h
+    # FAST reads every pyramid pixel once: in the fused per-cell kernel ("nms_compact" group, the
+    # "fast_measure" group then has no launches) or in the separate measure kernel.
+    fused = acc["fast_measure"][1] == 0
+    alg = {"level0": 2 * lvl0, "resize": 2 * (P - lvl0), "fast_measure": 0 if fused else P,
+           "nms_compact": P if fused else 0, "select": 0, "orient": 0, "blur": 2 * P, "describe": 60 * N_frame}
+    names = dict(KERNEL_OF_STAGE, nms_compact="k_fast_cell" if fused else "k_nms")
+    stage_ms = {s: a[0] / prof_steps for s, a in acc.items()}
+    dominant = max(stage_ms, key=stage_ms.get)
+    launches = acc[dominant][1] // prof_steps
+    avg_launch_ms = stage_ms[dominant] / max(launches, 1)
+    bytes_per_launch = alg[dominant] * wl.batch / max(launches, 1)
+    achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    path_bytes = (5 * P + 60 * N_frame) * wl.batch
+    path_ms = sum(stage_ms.values())
+    stages = {}
+    for s, ms in stage_ms.items():
+        b = alg[s] * wl.batch
+        stages[s] = {"kernel": names[s], "ms_per_step": round(ms, 4), "launches_per_step": acc[s][1] // prof_steps,
+                     "algorithmic_bytes_per_step": int(b),
+                     "achieved_gb_per_sec": round(b / (ms * 1e-3) / 1e9, 1) if ms > 0 and b else None,
+                     "frac": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms > 0 and b else None}
+    return {"bound": "hbm", "kernel": names[dominant], "stage": dominant, "achieved": round(achieved, 2),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": _pmc_traffic(names[dominant], wl),
+            "launches_per_step": launches, "avg_launch_ms": round(avg_launch_ms, 5),
+            "algorithmic_bytes_per_launch": int(bytes_per_launch),
+            "stages": stages,
+            "whole_path": {"algorithmic_bytes_per_step": int(path_bytes), "kernel_ms_per_step": round(path_ms, 4),
+                           "achieved": round(path_bytes / (path_ms * 1e-3) / 1e9, 2) if path_ms > 0 else 0.0,
+                           "frac": round(path_bytes / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if path_ms > 0 else 0.0}}, N_frame
+
+
+class Watchdog:
+    """The legs that run after the headline measurement must not be able to lose it: if they have not
+    finished after `seconds` (a collective that never completes, a stuck host thread), rank 0 prints the
+    line it has and every rank leaves."""
+
+    def __init__(self, seconds, rank):
+        self.line = None
+        self.rank = rank
+        self.timer = threading.Timer(seconds, self.fire)
+        self.timer.daemon = True
+        self.seconds = seconds
+
+    def arm(self, line):
+        self.line = line
+        self.timer.start()
+
+    def fire(self):
+        if self.rank == 0 and self.line is not None:
+            self.line["extra"] = {"error": "the legs after the headline measurement did not finish within %d s" % self.seconds}
+            print(json.dumps(self.line), flush=True)
+        os._exit(0)
+
+    def cancel(self):
+        self.timer.cancel()
 
 
 def main():
@@ -111,11 +233,14 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
-    ap.add_argument("--width", type=int, default=1280)
-    ap.add_argument("--height", type=int, default=720)
-    ap.add_argument("--features", type=int, default=2000)
-    ap.add_argument("--cpu-sample", type=int, default=96, help="frames of the CPU baseline sample")
-    ap.add_argument("--no-extra", action="store_true", help="skip the 640x480 and Hamming kNN legs")
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--features", type=int, default=1000)
+    ap.add_argument("--cpu-sample", type=int, default=256, help="frames of the CPU baseline sample")
+    ap.add_argument("--no-extra", action="store_true", help="headline measurement only")
+    ap.add_argument("--dist-legs", action="store_true",
+                    help="run the multi-rank legs even with one rank (rehearsal of the N > 1 code on one GPU)")
+    ap.add_argument("--legs-timeout", type=int, default=900, help="seconds the legs after the headline may take")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -136,13 +261,22 @@ def main():
         raise SystemExit("bench.py needs a GPU")
     dev = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev)
-    if world > 1:
+    use_dist = world > 1 or args.dist_legs
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
+
+    def max_over_ranks(x):
+        if not use_dist:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda:%d" % dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     wl = ExtractWorkload(orb, torch, dev, args.width, args.height, args.features, args.batch, first_idx=rank * args.batch)
 
@@ -157,85 +291,14 @@ def main():
     wl.sync()
     torch.cuda.synchronize()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda:%d" % dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     frames_total = args.batch * args.steps * world
     value = frames_total / elapsed
 
+    dog = Watchdog(args.legs_timeout, rank)
     out = None
     if rank == 0:
-        # ---- roofline of the dominant kernel group: separate profiled pass ----------------------
-        nl = wl.ext.GetLevels()
-        P = pyramid_pixels(wl.ext, nl)
-        wl.ext.set_profiling(True)
-        prof_steps = max(3, min(args.steps, 10))
-        acc = {}
-        for _ in range(prof_steps):
-            wl.step()
-            wl.sync()
-            for s, (ms, n) in wl.ext.stage_times().items():
-                a = acc.setdefault(s, [0.0, 0])
-                a[0] += ms
-                a[1] += n
-        wl.ext.set_profiling(False)
-        n_kp = int(wl.d_n.sum().item())
-        # algorithmic bytes per frame of each kernel group: the 5 B/pixel + 60 B/keypoint of the
-        # whole path split by who must move them (pyramid: read + write; FAST: read; blur: read +
-        # write; outputs: 32 B descriptor + 28 B keypoint).
-        N_frame = n_kp / args.batch
-        lvl0 = args.width * args.height
-        # FAST reads every pyramid pixel once: in the fused per-cell kernel ("nms_compact" group, the
-        # "fast_measure" group then has no launches) or in the separate measure kernel.
-        fused = acc["fast_measure"][1] == 0
-        alg = {"level0": 2 * lvl0, "resize": 2 * (P - lvl0), "fast_measure": 0 if fused else P,
-               "nms_compact": P if fused else 0, "select": 0, "orient": 0, "blur": 2 * P, "describe": 60 * N_frame}
-        stage_ms = {s: a[0] / prof_steps for s, a in acc.items()}
-        dominant = max(stage_ms, key=stage_ms.get)
-        launches = acc[dominant][1] // prof_steps
-        avg_launch_ms = stage_ms[dominant] / max(launches, 1)
-        bytes_per_launch = alg[dominant] * args.batch / max(launches, 1)
-        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-        path_bytes = (5 * P + 60 * N_frame) * args.batch
-        path_ms = sum(stage_ms.values())
-        kernel_names = {"level0": "k_level0", "resize": "k_resize", "fast_measure": "k_score",
-                        "nms_compact": "k_fast_cell" if fused else "k_nms", "select": "k_cell_select", "orient": "k_orient_describe",
-                        "blur": "k_blur", "describe": "k_orient_describe"}
-        roofline = {"bound": "hbm", "kernel": kernel_names[dominant], "stage": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": _pmc_traffic(kernel_names[dominant], args),
-                    "launches_per_step": launches, "avg_launch_ms": round(avg_launch_ms, 5),
-                    "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                    "stage_ms_per_step": {s: round(v, 4) for s, v in stage_ms.items()},
-                    "whole_path": {"algorithmic_bytes_per_step": int(path_bytes), "kernel_ms_per_step": round(path_ms, 4),
-                                   "achieved": round(path_bytes / (path_ms * 1e-3) / 1e9, 2) if path_ms > 0 else 0.0,
-                                   "frac": round(path_bytes / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if path_ms > 0 else 0.0}}
-
-        # ---- CPU baseline on a bounded sample of the same frames + parity of that sample --------
-        threads = max(1, min(16, os.cpu_count() or 1))
-        if world > 1:  # the CPU baseline and the extra legs belong to the N = 1 run; the other ranks are waiting
-            args.cpu_sample, args.no_extra = 0, True
-        cpu_fps, ref_results = cpu_baseline(wl.host, args.features, threads, args.cpu_sample) if args.cpu_sample > 0 else (0.0, [])
-        kp = wl.d_kp.cpu().numpy().view(np.uint32)
-        desc = wl.d_desc.cpu().numpy()
-        ncount = wl.d_n.cpu().numpy()
-        mism = 0
-        for i, (rkp, rdesc) in enumerate(ref_results):
-            n = len(rkp)
-            same = ncount[i] == n and np.array_equal(kp[i, :n].reshape(-1), rkp.view(np.uint32).reshape(-1)) \
-                and np.array_equal(desc[i, :n], rdesc)
-            mism += 0 if same else 1
-        cpu = None if not ref_results else {"value": round(cpu_fps, 3), "unit": "frames/s", "cores": threads, "kind": "port",
-               "sample": "%d of the %d frames of this workload (%dx%d, %d features), one oracle extractor per thread"
-                         % (len(ref_results), args.batch, args.width, args.height, args.features),
-               "parity_frames_checked": len(ref_results), "parity_frames_mismatching": mism}
-
-        extra = {}
-        if not args.no_extra:
-            extra = extra_legs(orb, torch, dev, threads)
-
+        roofline, N_frame = extract_roofline(wl, max(3, min(args.steps, 10)))
         out = {"metric": "orb_extract_frames_per_sec", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
@@ -243,66 +306,59 @@ def main():
                                       "full extract+describe" % (args.batch, args.width, args.height, args.features),
                           "frames_per_gpu_per_step": args.batch, "keypoints_per_frame": round(N_frame, 1),
                           "parallelism": "frame-batch sharding x%d, no data-path collective" % world},
-               "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
+               "roofline": roofline, "cpu_baseline": None, "extra": {}}
+    dog.arm(out)
+
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        # ---- CPU baseline on a bounded sample of the same frames + parity of that sample ------------
+        threads = max(1, min(16, os.cpu_count() or 1))
+        cpu1, ref_results = cpu_extract(wl.host, args.features, 1, args.cpu_sample)
+        cpuN, _ = cpu_extract(wl.host, args.features, threads, args.cpu_sample)
+        out["cpu_baseline"] = {
+            "value": round(cpu1, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d of the %d frames of this workload (%dx%d, %d features), the oracle extractor on one thread "
+                      "(the reference runs the path on one thread per frame)"
+                      % (len(ref_results), args.batch, args.width, args.height, args.features),
+            "all_cores": {"value": round(cpuN, 3), "cores": threads, "sample": "the same frames, one oracle extractor per thread"},
+            "gpu_over_cpu_1_thread": round(value / cpu1, 1), "gpu_over_cpu_all_cores": round(value / cpuN, 1),
+            "parity_frames_checked": len(ref_results), "parity_frames_mismatching": wl.mismatching(ref_results)}
+
+    if not args.no_extra:
+        if use_dist:
+            legs = dist_legs(orb, torch, dist, dev, rank, world, barrier, max_over_ranks)
+        else:
+            legs = single_gpu_legs(orb, torch, dev, wl)
+        if rank == 0:
+            out["extra"] = legs
     barrier()
+    dog.cancel()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
-def extra_legs(orb, torch, dev, threads):
-    """Not the headline value: the 640x480 / 1000-feature and 1920x1080 / 4000-feature extraction rates (the
-    reference's own CPU-runnable case and the per-GPU shard of the 2048-frame configuration), the Hamming kNN
-    rates (4096 frame pairs; one map shard), the windowed / projection matchers and the BoW legs."""
-    res = {}
-    # extraction, 640x480, 1000 features, batch 256
-    b = 256
-    wl = ExtractWorkload(orb, torch, dev, 640, 480, 1000, b, first_idx=100000)
-    for _ in range(2):
-        wl.step()
-    wl.sync()
-    t0 = time.perf_counter()
-    k = 10
-    for _ in range(k):
-        wl.step()
-    wl.sync()
-    dt = time.perf_counter() - t0
-    fps = b * k / dt
-    cpu1, _ = cpu_baseline(wl.host, 1000, 1, 24)
-    cpuN, _ = cpu_baseline(wl.host, 1000, threads, 16 * threads)
-    res["extract_640x480_1000"] = {"frames_per_sec": round(fps, 1), "batch": b,
-                                   "cpu_oracle_1_thread_frames_per_sec": round(cpu1, 2),
-                                   "cpu_oracle_%d_threads_frames_per_sec" % threads: round(cpuN, 2),
-                                   "speedup_vs_1_thread": round(fps / cpu1, 1)}
-    del wl
-    # extraction, 1920x1080, 4000 features, batch 256: the shard one GPU of eight owns in the 2048-frame
-    # configuration (32 distinct frames, repeated: host generation of 256 such frames would take longer than the run)
-    b3 = 256
-    f3 = np.concatenate([make_frames(orb.synth, 1920, 1080, 32, 300000)] * (b3 // 32))
-    wl = ExtractWorkload(orb, torch, dev, 1920, 1080, 4000, b3, first_idx=0, frames=f3)
-    for _ in range(2):
-        wl.step()
-    wl.sync()
-    t0 = time.perf_counter()
-    for _ in range(5):
-        wl.step()
-    wl.sync()
-    dt3 = time.perf_counter() - t0
-    nl3 = wl.ext.GetLevels()
-    bytes3 = 5 * pyramid_pixels(wl.ext, nl3) + 60 * float(wl.d_n.float().mean().item())
-    res["extract_1920x1080_4000"] = {"frames_per_sec": round(b3 * 5 / dt3, 1), "batch": b3, "ms_per_step": round(dt3 / 5 * 1e3, 3),
-                                     "algorithmic_gb_per_sec": round(b3 * 5 / dt3 * bytes3 / 1e9, 1),
-                                     "keypoints_per_frame": round(float(wl.d_n.float().mean().item()), 1)}
-    del wl, f3
-    # Hamming kNN k=2: 4096 pairs of 2000 x 2000 descriptors (1.6384e10 comparisons)
-    m = orb.ORBmatcher(0.6, True, device=dev)
-    pairs, nq, nt = 4096, 2000, 2000
-    g = torch.Generator(device="cuda:%d" % dev)
+# ------------------------------------------------------------------------------------------------
+# Hamming kNN helpers
+# ------------------------------------------------------------------------------------------------
+
+def knn_roofline(rate, r_bcnt, kernel="k_knn2"):
+    """One comparison = 8 v_xor + 8 v_bcnt lane-ops; the bound is the popcount rate the device sustains
+    (measured live by the library with every CU busy), the nominal figure is CUs x 64 lanes x clock."""
+    nominal = 256 * 64 * 2.4e9
+    return {"bound": "valu_popcount", "kernel": kernel, "achieved": float("%.4g" % (rate * 8)),
+            "peak": float("%.4g" % r_bcnt), "unit": "v_bcnt lane-ops/s", "frac": round(rate * 8 / r_bcnt, 4) if r_bcnt else None,
+            "nominal_peak": float("%.4g" % nominal), "frac_of_nominal": round(rate * 8 / nominal, 4)}
+
+
+def knn_pairs_leg(orb, torch, dev, m, pairs=4096, nq=2000, nt=2000, reps=5):
+    """4096 independent pairs of 2000 x 2000 descriptors: returns (median ms, device tensors)."""
+    cuda = "cuda:%d" % dev
+    g = torch.Generator(device=cuda)
     g.manual_seed(1)
-    q = torch.randint(0, 256, (pairs, nq, 32), dtype=torch.uint8, device="cuda:%d" % dev, generator=g)
-    t = torch.randint(0, 256, (pairs, nt, 32), dtype=torch.uint8, device="cuda:%d" % dev, generator=g)
-    o = torch.zeros((3, pairs, nq), dtype=torch.int32, device="cuda:%d" % dev)
+    q = torch.randint(0, 256, (pairs, nq, 32), dtype=torch.uint8, device=cuda, generator=g)
+    t = torch.randint(0, 256, (pairs, nt, 32), dtype=torch.uint8, device=cuda, generator=g)
+    o = torch.zeros((3, pairs, nq), dtype=torch.int32, device=cuda)
     torch.cuda.synchronize(dev)
 
     def run():
@@ -312,42 +368,153 @@ def extra_legs(orb, torch, dev, threads):
     run()
     m.synchronize()
     ms = []
-    for _ in range(5):
+    for _ in range(reps):
         run()
         m.synchronize()
         ms.append(m.last_elapsed_ms())
-    best = float(np.median(ms))
-    comps = pairs * nq * nt
-    rate = comps / (best * 1e-3)
-    # denominators measured live on this device (sustained, every CU busy): v_bcnt_u32_b32 issues at
-    # half the rate of v_add_u32 / v_xor_b32 on gfx950, so one comparison costs 8 xor slots + 16 bcnt
-    # slots + 3 slots of top-2 bookkeeping = 27 full-rate issue slots
-    r_bcnt, r_mix, r_add = m.valu_rate(0), m.valu_rate(1), m.valu_rate(2)
-    nominal = 256 * 4 * 32 * 2.4e9  # CUs x SIMDs x lanes/clk x clock
-    # CPU: scalar scan of the oracle on one pair, one thread
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import orbref
-    hq, ht = q[0].cpu().numpy(), t[0].cpu().numpy()
+    return float(np.median(ms)), run, q, t, o
+
+
+def cpu_knn(orbref, q, t, threads):
+    """Scalar scan of the oracle: `threads` pairs in parallel (ctypes releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
     t0 = time.perf_counter()
-    ridx, rd1, rd2 = orbref.knn2(hq, ht)
-    cdt = time.perf_counter() - t0
-    oo = o[:, 0].cpu().numpy()
+    with ThreadPoolExecutor(threads) as pool:
+        res = list(pool.map(lambda i: orbref.knn2(q[i], t[i]), range(len(q))))
+    return len(q) * q.shape[1] * t.shape[1] / (time.perf_counter() - t0), res
+
+
+# ------------------------------------------------------------------------------------------------
+# N = 1: everything else the library does, beside the headline
+# ------------------------------------------------------------------------------------------------
+
+def single_gpu_legs(orb, torch, dev, wl0):
+    orbref = oracle()
+    threads = max(1, min(16, os.cpu_count() or 1))
+    res = {}
+    cuda = "cuda:%d" % dev
+
+    # ---- host buffers in, host buffers out (PCIe inclusive), same 256 frames ---------------------
+    import ctypes as C
+    L = orb._lib.lib()
+    b, cap = wl0.batch, wl0.nf
+    kp = np.zeros((b, cap), dtype=orb.KP_DTYPE)
+    desc = np.zeros((b, cap, 32), dtype=np.uint8)
+    n = np.zeros(b, dtype=np.int32)
+
+    def host_batch():
+        orb._lib.check(L.orbhip_extract_batch(wl0.ext._h, wl0.host.ctypes.data_as(C.c_void_p), b, wl0.h, wl0.w, wl0.w,
+                                              wl0.w * wl0.h, kp.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.c_void_p),
+                                              cap, n.ctypes.data_as(C.c_void_p)))
+
+    host_batch()
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        host_batch()
+        ts.append(time.perf_counter() - t0)
+    dn = wl0.d_n.cpu().numpy()
+    same = np.array_equal(n, dn) and all(
+        np.array_equal(desc[i, :n[i]], wl0.d_desc[i, :n[i]].cpu().numpy()) for i in range(0, b, 37))
+    res["extract_host_buffers_pcie_inclusive"] = {
+        "frames_per_sec": round(b / float(np.median(ts)), 1), "batch": b, "ms_per_batch": round(float(np.median(ts)) * 1e3, 3),
+        "what": "orbhip_extract_batch: pageable host images in, keypoints and descriptors back in host memory, "
+                "one blocking call per %d frames" % b,
+        "same_output_as_device_path": bool(same)}
+
+    # ---- one frame per call: the call of src/Frame.cc:61 ------------------------------------------
+    one = orb.ORBextractor(wl0.nf, 1.2, 8, 1, 20, device=dev, max_width=wl0.w, max_height=wl0.h, max_batch=1)
+    img = wl0.host[0]
+    kp1 = np.zeros(cap, dtype=orb.KP_DTYPE)
+    d1 = np.zeros((cap, 32), dtype=np.uint8)
+    n1 = C.c_int(0)
+
+    def one_call():
+        orb._lib.check(L.orbhip_extract(one._h, img.ctypes.data_as(C.c_void_p), wl0.h, wl0.w, wl0.w,
+                                        kp1.ctypes.data_as(C.c_void_p), d1.ctypes.data_as(C.c_void_p), cap, C.byref(n1)))
+
+    for _ in range(20):
+        one_call()
+    ts = []
+    for _ in range(300):
+        t0 = time.perf_counter()
+        one_call()
+        ts.append(time.perf_counter() - t0)
+    rext = orbref.RefExtractor(wl0.nf, 1.2, 8, 1, 20)
+    rext(img)
+    tc = []
+    for _ in range(20):
+        t0 = time.perf_counter()
+        rext(img)
+        tc.append(time.perf_counter() - t0)
+    lat = {"calls": 300, "c_abi_median_us": round(float(np.median(ts)) * 1e6, 1),
+           "c_abi_p90_us": round(float(np.percentile(ts, 90)) * 1e6, 1),
+           "cpu_oracle_1_thread_median_us": round(float(np.median(tc)) * 1e6, 1),
+           "what": "orbhip_extract on one %dx%d frame in host memory, %d features, results back in host memory"
+                   % (wl0.w, wl0.h, wl0.nf)}
+    exe = os.path.join(ROOT, "orb-slam2_amd", "shim", "shim_test")
+    if os.path.exists(exe):
+        with tempfile.TemporaryDirectory() as td:
+            raw = os.path.join(td, "in.raw")
+            img.tofile(raw)
+            try:
+                r = subprocess.run([exe, "--latency", raw, str(wl0.h), str(wl0.w), str(wl0.nf), "300"], capture_output=True,
+                                   text=True, timeout=120)
+                j = json.loads(r.stdout.strip().splitlines()[-1])
+                lat["cpp_class_median_us"] = j["median_us"]
+                lat["cpp_class_p90_us"] = j["p90_us"]
+                lat["cpp_class_what"] = "ORB_SLAM::ORBextractor::operator() of the forwarding C++ class, 300 calls (shim_test --latency)"
+            except (OSError, ValueError, IndexError, KeyError, subprocess.SubprocessError) as e:
+                lat["cpp_class_error"] = repr(e)[:200]
+    res["single_frame_latency"] = lat
+    del one
+
+    # ---- the two larger extraction configurations, with their stage rooflines -----------------------
+    for name, w, h, nf, first, distinct in (("extract_1280x720_2000", 1280, 720, 2000, 0, 256),
+                                             ("extract_1920x1080_4000", 1920, 1080, 4000, 300000, 32)):
+        # 1080p: 32 distinct frames, repeated (host generation of 256 such frames would take longer than the run);
+        # it is the shard one GPU of eight owns in the 2048-frame configuration
+        bb = 256
+        fr = np.concatenate([make_frames(orb.synth, w, h, distinct, first)] * (bb // distinct))
+        wl = ExtractWorkload(orb, torch, dev, w, h, nf, bb, first_idx=0, frames=fr)
+        k = 10 if w < 1500 else 5
+        dt = wl.timed(k, 2)
+        roof, nkp = extract_roofline(wl, 3)
+        rr = [orbref.RefExtractor(nf, 1.2, 8, 1, 20)(fr[i]) for i in range(2)]
+        res[name] = {"frames_per_sec": round(bb * k / dt, 1), "batch": bb, "ms_per_step": round(dt / k * 1e3, 3),
+                     "keypoints_per_frame": round(nkp, 1), "roofline": roof,
+                     "parity_frames_checked": 2, "parity_frames_mismatching": wl.mismatching(rr)}
+        del wl, fr
+
+    # ---- Hamming kNN k=2: 4096 pairs of 2000 x 2000 descriptors (1.6384e10 comparisons) ------------
+    m = orb.ORBmatcher(0.6, True, device=dev)
+    pairs, nq, nt = 4096, 2000, 2000
+    best, _, q, t, o = knn_pairs_leg(orb, torch, dev, m, pairs, nq, nt)
+    rate = pairs * nq * nt / (best * 1e-3)
+    # denominators measured live on this device (sustained, every CU busy)
+    r_bcnt, r_mix, r_add = m.valu_rate(0), m.valu_rate(1), m.valu_rate(2)
+    hq, ht = q[:threads].cpu().numpy(), t[:threads].cpu().numpy()
+    cpu1, r1 = cpu_knn(orbref, hq[:1], ht[:1], 1)
+    cpuN, rN = cpu_knn(orbref, hq, ht, threads)
+    oo = o[:, :threads].cpu().numpy()
+    ok = all(np.array_equal(oo[0, i], rN[i][0]) and np.array_equal(oo[1, i], rN[i][1]) and np.array_equal(oo[2, i], rN[i][2])
+             for i in range(len(rN)))
     res["hamming_knn2"] = {"pairs": pairs, "nq": nq, "nt": nt, "comparisons_per_sec": float("%.4g" % rate),
-                           "ms": round(best, 4),
+                           "ms": round(best, 4), "roofline": knn_roofline(rate, r_bcnt),
                            "sustained_lane_ops_per_sec": {"v_bcnt_u32_b32": float("%.4g" % r_bcnt),
                                                           "xor_bcnt_mix": float("%.4g" % r_mix),
-                                                          "v_add_u32": float("%.4g" % r_add),
-                                                          "nominal_full_rate": float("%.4g" % nominal)},
-                           "popcount_frac_of_sustained_bcnt_peak": round(rate * 8 / r_bcnt, 4) if r_bcnt else None,
-                           "issue_slot_frac_of_sustained_valu": round(rate * 27 / r_add, 4) if r_add else None,
-                           "cpu_oracle_1_thread_comparisons_per_sec": float("%.4g" % (nq * nt / cdt)),
-                           "parity_pair0": bool(np.array_equal(oo[0], ridx) and np.array_equal(oo[1], rd1)
-                                                and np.array_equal(oo[2], rd2))}
-    # frame-vs-map shard: 4000 queries against the 1.25 M map descriptors one GPU of eight would own
+                                                          "v_add_u32": float("%.4g" % r_add)},
+                           "cpu_oracle_1_thread_comparisons_per_sec": float("%.4g" % cpu1),
+                           "cpu_oracle_%d_threads_comparisons_per_sec" % threads: float("%.4g" % cpuN),
+                           "parity_pairs_checked": len(rN), "parity": bool(ok)}
+    del q, t, o
+    # ---- frame-vs-map shard: 4000 queries against the 1.25 M map rows one GPU of eight owns ---------
     nq2, nt2 = 4000, 1250000
-    q2 = torch.randint(0, 256, (nq2, 32), dtype=torch.uint8, device="cuda:%d" % dev, generator=g)
-    t2 = torch.randint(0, 256, (nt2, 32), dtype=torch.uint8, device="cuda:%d" % dev, generator=g)
-    o2 = torch.zeros((3, nq2), dtype=torch.int32, device="cuda:%d" % dev)
+    g = torch.Generator(device=cuda)
+    g.manual_seed(2)
+    q2 = torch.randint(0, 256, (nq2, 32), dtype=torch.uint8, device=cuda, generator=g)
+    t2 = torch.randint(0, 256, (nt2, 32), dtype=torch.uint8, device=cuda, generator=g)
+    o2 = torch.zeros((3, nq2), dtype=torch.int32, device=cuda)
     torch.cuda.synchronize(dev)
     ms2 = []
     for _ in range(4):
@@ -355,17 +522,149 @@ def extra_legs(orb, torch, dev, threads):
         m.synchronize()
         ms2.append(m.last_elapsed_ms())
     best2 = float(np.median(ms2[1:]))
-    # spot check of 8 queries against the scalar scan
-    hq2, ht2 = q2[:8].cpu().numpy(), t2.cpu().numpy()
+    hq2, ht2 = q2[:16].cpu().numpy(), t2.cpu().numpy()
     r_idx, r_d1, r_d2 = orbref.knn2(hq2, ht2)
-    oo2 = o2[:, :8].cpu().numpy()
+    oo2 = o2[:, :16].cpu().numpy()
+    rate2 = nq2 * nt2 / (best2 * 1e-3)
     res["hamming_knn2_map_shard"] = {"nq": nq2, "nt": nt2, "ms": round(best2, 4),
-                                     "comparisons_per_sec": float("%.4g" % (nq2 * nt2 / (best2 * 1e-3))),
-                                     "parity_first_8_queries": bool(np.array_equal(oo2[0], r_idx) and np.array_equal(oo2[1], r_d1)
-                                                                    and np.array_equal(oo2[2], r_d2))}
+                                     "comparisons_per_sec": float("%.4g" % rate2), "roofline": knn_roofline(rate2, r_bcnt),
+                                     "parity_queries_checked": 16,
+                                     "parity": bool(np.array_equal(oo2[0], r_idx) and np.array_equal(oo2[1], r_d1)
+                                                    and np.array_equal(oo2[2], r_d2))}
     del q2, t2
     res["windowed_matchers"] = windowed_leg(orb, torch, dev, orbref)
     res["bow_transform"] = bow_leg(orb, torch, dev, orbref, m)
+    return res
+
+
+# ------------------------------------------------------------------------------------------------
+# N > 1: the rank-local legs of the multi-GPU configurations
+# ------------------------------------------------------------------------------------------------
+
+def dist_legs(orb, torch, dist, dev, rank, world, barrier, max_over_ranks):
+    """Every rank runs these; rank 0 returns the record.  Timing as for the headline: barrier and device
+    synchronisation on both sides, MAX over ranks."""
+    cuda = "cuda:%d" % dev
+    shard_range = orb.sharded.shard_range
+    res = {"ranks": world}
+
+    def timed(fn, sync, steps, warmup=1):
+        for _ in range(warmup):
+            fn()
+        sync()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        sync()
+        torch.cuda.synchronize()
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0)
+
+    # ---- frame-pair kNN: 4096 pairs of 2000 x 2000 per rank, no collective (weak scaling) -----------
+    m = orb.ORBmatcher(0.6, True, device=dev)
+    pairs, nq, nt = 4096, 2000, 2000
+    _, run, q, t, o = knn_pairs_leg(orb, torch, dev, m, pairs, nq, nt, reps=1)
+    steps = 3
+    dt = timed(run, m.synchronize, steps)
+    rate = world * pairs * nq * nt * steps / dt
+    r_bcnt = m.valu_rate(0)
+    if rank == 0:
+        orbref = oracle()
+        ridx, rd1, rd2 = orbref.knn2(q[0].cpu().numpy(), t[0].cpu().numpy())
+        oo = o[:, 0].cpu().numpy()
+        res["hamming_knn2_pairs"] = {
+            "scaling": "weak", "pairs_per_rank": pairs, "nq": nq, "nt": nt, "steps": steps,
+            "comparisons_per_sec": float("%.4g" % rate), "ms_per_step": round(dt / steps * 1e3, 3),
+            "roofline": knn_roofline(rate / world, r_bcnt), "collective": None,
+            "parity_pair0": bool(np.array_equal(oo[0], ridx) and np.array_equal(oo[1], rd1) and np.array_equal(oo[2], rd2))}
+    del q, t, o, run
+
+    # ---- 2048 frames of 1920x1080 / 4000 features, contiguous split (strong scaling) ----------------
+    total, w, h, nf, distinct = 2048, 1920, 1080, 4000, 32
+    f0, f1 = shard_range(total, rank, world)
+    pool = make_frames(orb.synth, w, h, distinct, 300000)  # frame i of the batch is pool[i % 32] on every rank
+    mine = np.stack([pool[i % distinct] for i in range(f0, f1)]) if f1 > f0 else np.zeros((0, h, w), np.uint8)
+    wl = ExtractWorkload(orb, torch, dev, w, h, nf, f1 - f0, first_idx=0, frames=mine, max_batch=256)
+    del mine
+    steps = 3
+    dt = timed(wl.step, wl.sync, steps)
+    if rank == 0:
+        rr = [oracle().RefExtractor(nf, 1.2, 8, 1, 20)(pool[(f0 + i) % distinct]) for i in range(2)]
+        P = pyramid_pixels(wl.ext, wl.ext.GetLevels())
+        nkp = float(wl.d_n.float().mean().item())
+        fps = total * steps / dt
+        res["extract_2048x1920x1080_4000"] = {
+            "scaling": "strong", "frames_total": total, "frames_this_rank": f1 - f0, "steps": steps,
+            "frames_per_sec": round(fps, 1), "ms_per_step": round(dt / steps * 1e3, 3), "keypoints_per_frame": round(nkp, 1),
+            "algorithmic_gb_per_sec": round(fps * (5 * P + 60 * nkp) / 1e9, 1),
+            "frac_of_hbm_peak_all_ranks": round(fps * (5 * P + 60 * nkp) / 1e9 / (HBM_PEAK_GBS * world), 5),
+            "collective": None, "parity_frames_checked": 2, "parity_frames_mismatching": wl.mismatching(rr)}
+    del wl, pool
+
+    # ---- 4000 queries against a 10 M-row map, one index-contiguous shard per rank --------------------
+    NT, nq = 10000000, 4000
+    planted = 64
+
+    def make_shard(r):
+        """Shard r of the map, the same bytes on whichever rank builds it.  Query i < 64 is planted as an
+        exact copy at row 1000 + 17 i of shard i % world and again further down in every later shard, so that
+        the first of several equal rows must win across the shard boundary."""
+        a, e = shard_range(NT, r, world)
+        g = torch.Generator(device=cuda)
+        g.manual_seed(5000 + r)
+        s = torch.randint(0, 256, (e - a, 32), dtype=torch.uint8, device=cuda, generator=g)
+        for i in range(planted):
+            if i % world == r:
+                s[1000 + 17 * i] = dq[i]
+            elif i % world < r:
+                s[(e - a) // 2 + 13 * i] = dq[i]
+        return a, e, s
+
+    g = torch.Generator(device=cuda)
+    g.manual_seed(99)
+    dq = torch.randint(0, 256, (nq, 32), dtype=torch.uint8, device=cuda, generator=g)  # replicated: same seed
+    a, e, shard = make_shard(rank)
+    out_c = torch.full((3, nq), -5, dtype=torch.int32, device=cuda)
+    out_t = torch.full((3, nq), -6, dtype=torch.int32, device=cuda)
+    parts_local = torch.zeros((3, nq), dtype=torch.int32, device=cuda)
+    parts_all = torch.zeros((world, 3, nq), dtype=torch.int32, device=cuda)
+    torch.cuda.synchronize()
+    comm = orb.sharded.Communicator.from_torch_distributed(dist, dev)
+    steps = 5
+    dt_c = timed(lambda: orb.sharded.knn2_sharded_rccl(m, comm, dq, nq, shard, e - a, a, out_c), m.synchronize, steps)
+    dt_t = timed(lambda: orb.sharded.knn2_sharded(m, dq, nq, shard, e - a, a, parts_local, parts_all, out_t, dist=dist),
+                 m.synchronize, steps)
+    comm.close()
+    same = torch.tensor([int(torch.equal(out_c, out_t))], dtype=torch.int32, device=cuda)
+    dist.all_reduce(same, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        orbref = oracle()
+        sample = np.concatenate([np.arange(0, planted, 4), np.arange(planted, planted + 8)])
+        hq = dq[torch.from_numpy(sample).to(cuda)].cpu().numpy()
+        hmap = np.empty((NT, 32), np.uint8)
+        for r in range(world):
+            ra, re_, s = make_shard(r)
+            hmap[ra:re_] = s.cpu().numpy()
+            del s
+        ridx, rd1, rd2 = orbref.knn2(hq, hmap)
+        oc = out_c.cpu().numpy()[:, sample]
+        ok = np.array_equal(oc[0], ridx) and np.array_equal(oc[1], rd1) and np.array_equal(oc[2], rd2)
+        first_wins = all(int(oc[0, k]) == shard_range(NT, int(i) % world, world)[0] + 1000 + 17 * int(i)
+                         for k, i in enumerate(sample) if i < planted)
+        rate = nq * NT * steps / dt_c
+        res["hamming_knn2_map_10M"] = {
+            "scaling": "strong", "nq": nq, "map_rows": NT, "rows_this_rank": e - a, "steps": steps,
+            "comparisons_per_sec": float("%.4g" % rate), "ms_per_step": round(dt_c / steps * 1e3, 3),
+            "roofline": knn_roofline(rate / world, r_bcnt),
+            "collective": "one ncclAllGather of 12 B x %d queries per rank over %d ranks (orbhip_knn2_sharded, the "
+                          "library's own RCCL communicator, queued on the matcher's stream)" % (nq, world),
+            "torch_distributed_form": {"ms_per_step": round(dt_t / steps * 1e3, 3),
+                                       "comparisons_per_sec": float("%.4g" % (nq * NT * steps / dt_t)),
+                                       "collective": "one all_gather_into_tensor on the nccl backend + device merge",
+                                       "same_result_on_every_rank": bool(int(same.item()))},
+            "parity_queries_checked": int(len(sample)), "parity": bool(ok), "first_of_equal_rows_wins_across_shards": bool(first_wins)}
     return res
 
 
@@ -546,6 +845,7 @@ def windowed_leg(orb, torch, dev, orbref):
                                                 "search_by_projection_last_frame_th15": round(4 / t_p, 1)}
     out["parity_first_4_pairs"] = bool(ok)
     return out
+
 
 
 if __name__ == "__main__":
