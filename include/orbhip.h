@@ -400,6 +400,31 @@ int orbhip_search_by_bow_device(orbhip_matcher* m, const OrbKeypoint* d_kp1, con
                                 int check_orientation, int th_low_inclusive, int32_t* d_matches12, int32_t* d_matches21,
                                 int32_t* d_nmatches);
 
+/* Host-pointer form of orbhip_search_by_bow_device for ONE pair (copy in, match, copy out; blocking): what a
+ * forwarding ORBmatcher::SearchByBoW (src/ORBmatcher.cc:158-295 with th_low_inclusive = 1 and valid2 = NULL,
+ * :726-861 with th_low_inclusive = 0) calls.  A DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned>>,
+ * Thirdparty/DBoW2/DBoW2/FeatureVector.h) arrives flattened in map order: fv_nodes[j] ascending, the features of
+ * node j at fv_feat[fv_start[j] ... fv_start[j+1]), fv_start[0] = 0.  matches12 (n1) / matches21 (n2) as in the
+ * device form. */
+int orbhip_search_by_bow(orbhip_matcher* m, const OrbKeypoint* kp1, const uint8_t* desc1, int n1, const uint8_t* valid1,
+                         const int32_t* fv1_nodes, const int32_t* fv1_start, const int32_t* fv1_feat, int fv1_count,
+                         const OrbKeypoint* kp2, const uint8_t* desc2, int n2, const uint8_t* valid2, const int32_t* fv2_nodes,
+                         const int32_t* fv2_start, const int32_t* fv2_feat, int fv2_count, float nnratio, int check_orientation,
+                         int th_low_inclusive, int32_t* matches12, int32_t* matches21, int32_t* nmatches);
+/* Host-pointer form of orbhip_distinctive_descriptors_device (blocking): the descriptor choice of
+ * MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:221-250) for npoints map points, start[0] = 0. */
+int orbhip_distinctive_descriptors(orbhip_matcher* m, const uint8_t* desc, const int32_t* start, int npoints, int32_t* best_idx,
+                                   int32_t* best_median);
+/* Host-pointer form of orbhip_undistort_keypoints_device for ONE frame (blocking): Frame::UndistortKeyPoints
+ * (src/Frame.cc:290-320), mvKeysUn from mvKeys.  kp_un == kp is allowed. */
+int orbhip_undistort_keypoints(orbhip_matcher* m, const OrbKeypoint* kp, int n, OrbCamera cam, OrbKeypoint* kp_un);
+/* Host-pointer form of orbhip_bow_transform_device (blocking): the per-feature part of
+ * mpORBvocabulary->transform(vCurrentDesc, mBowVec, mFeatVec, 4) in Frame::ComputeBoW (src/Frame.cc:281-288);
+ * the caller accumulates BowVector / FeatureVector from the triples in feature order
+ * (TemplatedVocabulary.h:1150-1163). */
+int orbhip_bow_transform(orbhip_matcher* m, const orbhip_vocabulary* v, const uint8_t* desc, int n, int levelsup, int32_t* word,
+                         int32_t* node, double* weight);
+
 /* Device self-tests of the arithmetic helpers (test instrumentation, host pointers, blocking):
  * which 0: n (y, x) float pairs -> n floats, the device's fastAtan2 in degrees
  *       1: n float angles (radians) -> n (cos, sin) float pairs as the descriptor kernel computes them

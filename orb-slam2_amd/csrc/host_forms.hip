@@ -1,0 +1,205 @@
+// Host-pointer forms of the entry points a C++ caller with host-resident data needs besides the
+// windowed / projection matchers: ORBmatcher::SearchByBoW (src/ORBmatcher.cc:158-295, :726-861),
+// MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:191-256), Frame::UndistortKeyPoints
+// (src/Frame.cc:290-320) and the per-feature vocabulary descent behind Frame::ComputeBoW (:281-288).
+// Each copies its arguments into a staging arena of the handle, runs the device entry point on the
+// matcher's stream and copies the results back (blocking).  No arithmetic of the path happens here.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+
+#include "../../include/orbhip.h"
+#include "common.h"
+#include "matcher_internal.h"
+
+namespace {
+
+// Carves 256-byte aligned pieces out of the handle's staging arena; reserve() grows the arena once all
+// pieces are known.
+struct Arena {
+    size_t off = 0;
+    size_t take(size_t bytes) {
+        const size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    }
+};
+
+int reserve_stage(orbhip_matcher* m, size_t bytes) {
+    if (bytes <= m->stage_bytes) return ORBHIP_OK;
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (m->d_stage) (void)hipFree(m->d_stage);
+    m->d_stage = nullptr;
+    m->stage_bytes = 0;
+    if (hipMalloc(&m->d_stage, bytes) != hipSuccess) return orb_fail(ORBHIP_ENOMEM, "hipMalloc of %zu bytes failed", bytes);
+    m->stage_bytes = bytes;
+    return ORBHIP_OK;
+}
+
+struct FvHost {
+    const int32_t *nodes, *start, *feat;
+    int count;
+};
+
+// A FeatureVector handed over as arrays must be what FeatureVector::addFeature builds: nodes strictly
+// ascending, starts non-decreasing from 0, feature indices inside the frame.
+int check_fv(const FvHost& fv, int n, const char* which) {
+    if (fv.count < 0) return orb_fail(ORBHIP_EINVAL, "%s: negative node count", which);
+    if (fv.count == 0) return ORBHIP_OK;
+    if (!fv.nodes || !fv.start || !fv.feat) return orb_fail(ORBHIP_EINVAL, "%s: null array", which);
+    if (fv.start[0] != 0) return orb_fail(ORBHIP_EINVAL, "%s: start[0] = %d", which, fv.start[0]);
+    for (int j = 0; j < fv.count; j++) {
+        if (j && fv.nodes[j] <= fv.nodes[j - 1]) return orb_fail(ORBHIP_EINVAL, "%s: node ids not ascending at %d", which, j);
+        if (fv.start[j + 1] < fv.start[j]) return orb_fail(ORBHIP_EINVAL, "%s: starts decrease at %d", which, j);
+    }
+    const int total = fv.start[fv.count];
+    if (total > n) return orb_fail(ORBHIP_EINVAL, "%s: %d feature entries for %d features", which, total, n);
+    for (int i = 0; i < total; i++)
+        if (fv.feat[i] < 0 || fv.feat[i] >= n) return orb_fail(ORBHIP_EINVAL, "%s: feature index %d of %d", which, fv.feat[i], n);
+    return ORBHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int orbhip_search_by_bow(orbhip_matcher* m, const OrbKeypoint* kp1, const uint8_t* desc1, int n1, const uint8_t* valid1,
+                         const int32_t* fv1_nodes, const int32_t* fv1_start, const int32_t* fv1_feat, int fv1_count,
+                         const OrbKeypoint* kp2, const uint8_t* desc2, int n2, const uint8_t* valid2, const int32_t* fv2_nodes,
+                         const int32_t* fv2_start, const int32_t* fv2_feat, int fv2_count, float nnratio, int check_orientation,
+                         int th_low_inclusive, int32_t* matches12, int32_t* matches21, int32_t* nmatches) {
+    if (!m) return orb_fail(ORBHIP_EINVAL, "null matcher");
+    if (n1 < 0 || n2 < 0) return orb_fail(ORBHIP_EINVAL, "negative size");
+    if (!nmatches || (n1 && (!kp1 || !desc1 || !valid1 || !matches12)) || (n2 && (!kp2 || !desc2 || !matches21)))
+        return orb_fail(ORBHIP_EINVAL, "null buffer");
+    const FvHost fv[2] = {{fv1_nodes, fv1_start, fv1_feat, fv1_count}, {fv2_nodes, fv2_start, fv2_feat, fv2_count}};
+    int rc;
+    if ((rc = check_fv(fv[0], n1, "first FeatureVector")) || (rc = check_fv(fv[1], n2, "second FeatureVector"))) return rc;
+    const int cap = std::max(1, std::max(n1, n2));
+    if (cap > ORBHIP_FRAME_MAX_KEYPOINTS) return orb_fail(ORBHIP_ECAP, "%d features > %d per frame", cap, ORBHIP_FRAME_MAX_KEYPOINTS);
+    const int node_cap = std::max(1, std::max(fv1_count, fv2_count));
+    HIPCHK(hipSetDevice(m->device));
+    Arena a;
+    size_t o_kp[2], o_d[2], o_v[2], o_nodes[2], o_start[2], o_feat[2];
+    for (int s = 0; s < 2; s++) {
+        o_kp[s] = a.take(sizeof(OrbKeypoint) * cap);
+        o_d[s] = a.take(32 * (size_t)cap);
+        o_v[s] = a.take(cap);
+        o_nodes[s] = a.take(sizeof(int32_t) * node_cap);
+        o_start[s] = a.take(sizeof(int32_t) * (node_cap + 1));
+        o_feat[s] = a.take(sizeof(int32_t) * cap);
+    }
+    const size_t o_n = a.take(sizeof(int32_t) * 4), o_m12 = a.take(sizeof(int32_t) * cap), o_m21 = a.take(sizeof(int32_t) * cap);
+    const size_t o_nm = a.take(sizeof(int32_t));
+    if ((rc = reserve_stage(m, a.off))) return rc;
+    char* b = (char*)m->d_stage;
+    const int32_t counts[4] = {n1, n2, fv1_count, fv2_count};
+    HIPCHK(hipMemcpyAsync(b + o_n, counts, sizeof(counts), hipMemcpyHostToDevice, m->stream));
+    const OrbKeypoint* kp[2] = {kp1, kp2};
+    const uint8_t* desc[2] = {desc1, desc2};
+    const uint8_t* valid[2] = {valid1, valid2};
+    const int n[2] = {n1, n2};
+    for (int s = 0; s < 2; s++) {
+        if (n[s]) {
+            HIPCHK(hipMemcpyAsync(b + o_kp[s], kp[s], sizeof(OrbKeypoint) * n[s], hipMemcpyHostToDevice, m->stream));
+            HIPCHK(hipMemcpyAsync(b + o_d[s], desc[s], 32 * (size_t)n[s], hipMemcpyHostToDevice, m->stream));
+            if (valid[s]) HIPCHK(hipMemcpyAsync(b + o_v[s], valid[s], n[s], hipMemcpyHostToDevice, m->stream));
+        }
+        if (fv[s].count) {
+            HIPCHK(hipMemcpyAsync(b + o_nodes[s], fv[s].nodes, sizeof(int32_t) * fv[s].count, hipMemcpyHostToDevice, m->stream));
+            HIPCHK(hipMemcpyAsync(b + o_start[s], fv[s].start, sizeof(int32_t) * (fv[s].count + 1), hipMemcpyHostToDevice, m->stream));
+            if (fv[s].start[fv[s].count])
+                HIPCHK(hipMemcpyAsync(b + o_feat[s], fv[s].feat, sizeof(int32_t) * fv[s].start[fv[s].count], hipMemcpyHostToDevice,
+                                      m->stream));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(m->stream));  // counts[] lives on this stack frame
+    const int32_t* d_n = (const int32_t*)(b + o_n);
+    rc = orbhip_search_by_bow_device(
+        m, (const OrbKeypoint*)(b + o_kp[0]), (const uint8_t*)(b + o_d[0]), d_n, (const uint8_t*)(b + o_v[0]),
+        (const int32_t*)(b + o_nodes[0]), (const int32_t*)(b + o_start[0]), (const int32_t*)(b + o_feat[0]), d_n + 2,
+        (const OrbKeypoint*)(b + o_kp[1]), (const uint8_t*)(b + o_d[1]), d_n + 1, valid2 ? (const uint8_t*)(b + o_v[1]) : nullptr,
+        (const int32_t*)(b + o_nodes[1]), (const int32_t*)(b + o_start[1]), (const int32_t*)(b + o_feat[1]), d_n + 3, 1, cap,
+        node_cap, nnratio, check_orientation, th_low_inclusive, (int32_t*)(b + o_m12), (int32_t*)(b + o_m21), (int32_t*)(b + o_nm));
+    if (rc) return rc;
+    if (n1) HIPCHK(hipMemcpyAsync(matches12, b + o_m12, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, m->stream));
+    if (n2) HIPCHK(hipMemcpyAsync(matches21, b + o_m21, sizeof(int32_t) * n2, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(nmatches, b + o_nm, sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+    return orbhip_matcher_synchronize(m);
+}
+
+int orbhip_distinctive_descriptors(orbhip_matcher* m, const uint8_t* desc, const int32_t* start, int npoints, int32_t* best_idx,
+                                   int32_t* best_median) {
+    if (!m) return orb_fail(ORBHIP_EINVAL, "null matcher");
+    if (npoints < 0) return orb_fail(ORBHIP_EINVAL, "negative size");
+    if (npoints == 0) return ORBHIP_OK;
+    if (!start || !best_idx || !best_median) return orb_fail(ORBHIP_EINVAL, "null buffer");
+    if (start[0] != 0) return orb_fail(ORBHIP_EINVAL, "start[0] = %d", start[0]);
+    for (int p = 0; p < npoints; p++)
+        if (start[p + 1] < start[p]) return orb_fail(ORBHIP_EINVAL, "starts decrease at point %d", p);
+    const int total = start[npoints];
+    if (total && !desc) return orb_fail(ORBHIP_EINVAL, "null descriptors");
+    HIPCHK(hipSetDevice(m->device));
+    Arena a;
+    const size_t o_d = a.take(32 * (size_t)std::max(total, 1)), o_s = a.take(sizeof(int32_t) * (npoints + 1));
+    const size_t o_i = a.take(sizeof(int32_t) * npoints), o_med = a.take(sizeof(int32_t) * npoints);
+    int rc = reserve_stage(m, a.off);
+    if (rc) return rc;
+    char* b = (char*)m->d_stage;
+    if (total) HIPCHK(hipMemcpyAsync(b + o_d, desc, 32 * (size_t)total, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(b + o_s, start, sizeof(int32_t) * (npoints + 1), hipMemcpyHostToDevice, m->stream));
+    if ((rc = orbhip_distinctive_descriptors_device(m, (const uint8_t*)(b + o_d), (const int32_t*)(b + o_s), npoints,
+                                                    (int32_t*)(b + o_i), (int32_t*)(b + o_med))))
+        return rc;
+    HIPCHK(hipMemcpyAsync(best_idx, b + o_i, sizeof(int32_t) * npoints, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(best_median, b + o_med, sizeof(int32_t) * npoints, hipMemcpyDeviceToHost, m->stream));
+    return orbhip_matcher_synchronize(m);
+}
+
+int orbhip_undistort_keypoints(orbhip_matcher* m, const OrbKeypoint* kp, int n, OrbCamera cam, OrbKeypoint* kp_un) {
+    if (!m) return orb_fail(ORBHIP_EINVAL, "null matcher");
+    if (n < 0) return orb_fail(ORBHIP_EINVAL, "negative size");
+    if (n == 0) return ORBHIP_OK;
+    if (!kp || !kp_un) return orb_fail(ORBHIP_EINVAL, "null buffer");
+    HIPCHK(hipSetDevice(m->device));
+    Arena a;
+    const size_t o_kp = a.take(sizeof(OrbKeypoint) * n), o_n = a.take(sizeof(int32_t));
+    int rc = reserve_stage(m, a.off);
+    if (rc) return rc;
+    char* b = (char*)m->d_stage;
+    const int32_t cnt = n;
+    HIPCHK(hipMemcpyAsync(b + o_n, &cnt, sizeof(cnt), hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(b + o_kp, kp, sizeof(OrbKeypoint) * n, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));  // cnt lives on this stack frame
+    if ((rc = orbhip_undistort_keypoints_device(m, (const OrbKeypoint*)(b + o_kp), (const int32_t*)(b + o_n), 1, n, cam,
+                                                (OrbKeypoint*)(b + o_kp))))
+        return rc;
+    HIPCHK(hipMemcpyAsync(kp_un, b + o_kp, sizeof(OrbKeypoint) * n, hipMemcpyDeviceToHost, m->stream));
+    return orbhip_matcher_synchronize(m);
+}
+
+int orbhip_bow_transform(orbhip_matcher* m, const orbhip_vocabulary* v, const uint8_t* desc, int n, int levelsup, int32_t* word,
+                         int32_t* node, double* weight) {
+    if (!m || !v) return orb_fail(ORBHIP_EINVAL, "null handle");
+    if (n < 0) return orb_fail(ORBHIP_EINVAL, "negative size");
+    if (n == 0) return ORBHIP_OK;
+    if (!desc || !word || !node || !weight) return orb_fail(ORBHIP_EINVAL, "null buffer");
+    HIPCHK(hipSetDevice(m->device));
+    Arena a;
+    const size_t o_d = a.take(32 * (size_t)n), o_w = a.take(sizeof(int32_t) * n), o_nd = a.take(sizeof(int32_t) * n);
+    const size_t o_wt = a.take(sizeof(double) * n);
+    int rc = reserve_stage(m, a.off);
+    if (rc) return rc;
+    char* b = (char*)m->d_stage;
+    HIPCHK(hipMemcpyAsync(b + o_d, desc, 32 * (size_t)n, hipMemcpyHostToDevice, m->stream));
+    if ((rc = orbhip_bow_transform_device(m, v, (const uint8_t*)(b + o_d), n, levelsup, (int32_t*)(b + o_w), (int32_t*)(b + o_nd),
+                                          (double*)(b + o_wt))))
+        return rc;
+    HIPCHK(hipMemcpyAsync(word, b + o_w, sizeof(int32_t) * n, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(node, b + o_nd, sizeof(int32_t) * n, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(weight, b + o_wt, sizeof(double) * n, hipMemcpyDeviceToHost, m->stream));
+    return orbhip_matcher_synchronize(m);
+}
+
+}  // extern "C"

@@ -10,7 +10,10 @@
 #else
 #include <opencv2/core/core.hpp>
 #endif
+#include <algorithm>
 #include <climits>
+#include <cmath>
+#include <set>
 #include <stdexcept>
 #include <vector>
 
@@ -136,6 +139,360 @@ struct ORBmatcherAccel {
         for (int i = 0; i < n; i++)
             if (owner[i] >= 0) F.mvpMapPoints[i] = vpMapPoints[owner[i]];
         return nmatches;
+    }
+
+    // ---- shared by the projection overloads below --------------------------------------------------
+    static void ClearProbe(OrbProbe& q) {
+        q.u = q.v = q.r = q.angle = 0.f;
+        q.min_level = q.max_level = q.valid = q.reserved = 0;
+    }
+    static void CopyDescriptor(const cv::Mat& d, unsigned char* dst) {
+        const unsigned char* p = d.ptr<unsigned char>(0);
+        for (int b = 0; b < 32; b++) dst[b] = p[b];
+    }
+    static std::vector<unsigned char> packRows(const cv::Mat& D) {
+        std::vector<unsigned char> d((size_t)(D.rows ? D.rows : 1) * 32);
+        for (int i = 0; i < D.rows; i++) CopyDescriptor(D.row(i), &d[(size_t)i * 32]);
+        return d;
+    }
+    // probes -> device search -> owner[i2] = probe index assigned to feature i2 (or -1)
+    int RunProbes(const std::vector<OrbProbe>& probes, const std::vector<unsigned char>& pdesc, int nprobes,
+                  const std::vector<cv::KeyPoint>& keys, const std::vector<unsigned char>& desc, const OrbFrameBounds& b,
+                  const std::vector<unsigned char>& taken, int rule, int thDist, bool checkOri, std::vector<int>& owner) {
+        const int n = (int)keys.size();
+        owner.assign(n ? n : 1, -1);
+        int nmatches = 0;
+        if (orbhip_search_by_projection(handle, probes.data(), pdesc.data(), nprobes, (const OrbKeypoint*)keys.data(), desc.data(),
+                                        n, b, taken.data(), rule, mfNNratio, thDist, checkOri, owner.data(), &nmatches) != ORBHIP_OK)
+            throw std::runtime_error(orbhip_last_error());
+        return nmatches;
+    }
+
+    // int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, vector<MapPoint*> &vpMatched, int th)
+    // (include/ORBmatcher.h:58, src/ORBmatcher.cc:297-418).  The pose decomposition and the per-point projection,
+    // depth, distance and viewing-angle tests stay the reference's lines; every point that passes them becomes a
+    // probe.  FrameT only supplies the image bounds every KeyFrame copies from it (src/KeyFrame.cc:44).
+    template <class FrameT, class KeyFrameT, class MapPointT>
+    int SearchByProjection(KeyFrameT* pKF, cv::Mat Scw, const std::vector<MapPointT*>& vpPoints,
+                           std::vector<MapPointT*>& vpMatched, int th) {
+        const float fx = pKF->fx, fy = pKF->fy, cx = pKF->cx, cy = pKF->cy;
+        const int nMaxLevel = pKF->GetScaleLevels() - 1;
+        std::vector<float> vfScaleFactors = pKF->GetScaleFactors();
+        cv::Mat sRcw = Scw.rowRange(0, 3).colRange(0, 3);
+        const float scw = sqrt(sRcw.row(0).dot(sRcw.row(0)));
+        cv::Mat Rcw = sRcw / scw;
+        cv::Mat tcw = Scw.rowRange(0, 3).col(3) / scw;
+        cv::Mat Ow = -Rcw.t() * tcw;
+        std::set<MapPointT*> spAlreadyFound(vpMatched.begin(), vpMatched.end());
+        spAlreadyFound.erase(static_cast<MapPointT*>(0));
+
+        const int nmp = (int)vpPoints.size();
+        std::vector<OrbProbe> probes(nmp ? nmp : 1);
+        std::vector<unsigned char> pdesc((size_t)(nmp ? nmp : 1) * 32);
+        for (int iMP = 0; iMP < nmp; iMP++) {
+            OrbProbe& q = probes[iMP];
+            ClearProbe(q);
+            MapPointT* pMP = vpPoints[iMP];
+            if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+            cv::Mat p3Dw = pMP->GetWorldPos();
+            cv::Mat p3Dc = Rcw * p3Dw + tcw;
+            if (p3Dc.template at<float>(2) < 0.0) continue;
+            const float invz = 1 / p3Dc.template at<float>(2);
+            const float x = p3Dc.template at<float>(0) * invz;
+            const float y = p3Dc.template at<float>(1) * invz;
+            const float u = fx * x + cx;
+            const float v = fy * y + cy;
+            if (!pKF->IsInImage(u, v)) continue;
+            const float maxDistance = pMP->GetMaxDistanceInvariance();
+            const float minDistance = pMP->GetMinDistanceInvariance();
+            cv::Mat PO = p3Dw - Ow;
+            const float dist = cv::norm(PO);
+            if (dist < minDistance || dist > maxDistance) continue;
+            cv::Mat Pn = pMP->GetNormal();
+            if (PO.dot(Pn) < 0.5 * dist) continue;
+            const float ratio = dist / minDistance;
+            std::vector<float>::iterator it = std::lower_bound(vfScaleFactors.begin(), vfScaleFactors.end(), ratio);
+            const int nPredictedLevel = std::min(static_cast<int>(it - vfScaleFactors.begin()), nMaxLevel);
+            q.u = u;
+            q.v = v;
+            q.r = th * pKF->GetScaleFactor(nPredictedLevel);
+            q.min_level = nPredictedLevel - 1;  // the kpLevel test of :392-395
+            q.max_level = nPredictedLevel;
+            q.valid = 1;
+            CopyDescriptor(pMP->GetDescriptor(), &pdesc[(size_t)iMP * 32]);
+        }
+        const std::vector<cv::KeyPoint> keys = pKF->GetKeyPointsUn();
+        const std::vector<unsigned char> desc = packRows(pKF->GetDescriptors());
+        const int n = (int)keys.size();
+        std::vector<unsigned char> taken(n ? n : 1);
+        for (int i = 0; i < n; i++) taken[i] = vpMatched[i] != 0;
+        const OrbFrameBounds b = {FrameT::mnMinX, FrameT::mnMinY, FrameT::mnMaxX, FrameT::mnMaxY};
+        std::vector<int> owner;
+        const int nmatches = RunProbes(probes, pdesc, nmp, keys, desc, b, taken, ORBHIP_PROJ_BEST, TH_LOW, false, owner);
+        for (int i = 0; i < n; i++)
+            if (owner[i] >= 0) vpMatched[i] = vpPoints[owner[i]];
+        return nmatches;
+    }
+
+    // int SearchByProjection(Frame &F1, Frame &F2, int windowSize, vector<MapPoint*> &vpMapPointMatches2)
+    // (include/ORBmatcher.h:66, src/ORBmatcher.cc:530-605)
+    template <class FrameT, class MapPointT>
+    int SearchByProjection(FrameT& F1, FrameT& F2, int windowSize, std::vector<MapPointT*>& vpMapPointMatches2) {
+        vpMapPointMatches2 = F2.mvpMapPoints;
+        std::set<MapPointT*> spMapPointsAlreadyFound(vpMapPointMatches2.begin(), vpMapPointMatches2.end());
+        const cv::Mat Rc2w = F2.mTcw.rowRange(0, 3).colRange(0, 3);
+        const cv::Mat tc2w = F2.mTcw.rowRange(0, 3).col(3);
+        const int n1 = (int)F1.mvpMapPoints.size();
+        std::vector<OrbProbe> probes(n1 ? n1 : 1);
+        for (int i1 = 0; i1 < n1; i1++) {
+            OrbProbe& q = probes[i1];
+            ClearProbe(q);
+            MapPointT* pMP1 = F1.mvpMapPoints[i1];
+            if (!pMP1) continue;
+            if (pMP1->isBad() || spMapPointsAlreadyFound.count(pMP1)) continue;
+            cv::KeyPoint kp1 = F1.mvKeysUn[i1];
+            int level1 = kp1.octave;
+            cv::Mat x3Dw = pMP1->GetWorldPos();
+            cv::Mat x3Dc2 = Rc2w * x3Dw + tc2w;
+            const float xc2 = x3Dc2.template at<float>(0);
+            const float yc2 = x3Dc2.template at<float>(1);
+            const float invzc2 = 1.0 / x3Dc2.template at<float>(2);
+            q.u = FrameT::fx * xc2 * invzc2 + FrameT::cx;
+            q.v = FrameT::fy * yc2 * invzc2 + FrameT::cy;
+            q.r = windowSize;
+            q.min_level = q.max_level = level1;
+            q.valid = 1;
+        }
+        const std::vector<unsigned char> pdesc = packDescriptors(F1), d2 = packDescriptors(F2);
+        const int n2 = (int)F2.mvKeysUn.size();
+        std::vector<unsigned char> taken(n2 ? n2 : 1);
+        for (int i = 0; i < n2; i++) taken[i] = vpMapPointMatches2[i] != 0;
+        const OrbFrameBounds b = {FrameT::mnMinX, FrameT::mnMinY, FrameT::mnMaxX, FrameT::mnMaxY};
+        std::vector<int> owner;
+        const int nmatches = RunProbes(probes, pdesc, n1, F2.mvKeysUn, d2, b, taken, ORBHIP_PROJ_RATIO, TH_HIGH, false, owner);
+        for (int i = 0; i < n2; i++)
+            if (owner[i] >= 0) vpMapPointMatches2[i] = F1.mvpMapPoints[owner[i]];
+        return nmatches;
+    }
+
+    // int SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, float th)
+    // (include/ORBmatcher.h:81, src/ORBmatcher.cc:1518-1631)
+    template <class FrameT>
+    int SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame, float th) {
+        const cv::Mat Rcw = CurrentFrame.mTcw.rowRange(0, 3).colRange(0, 3);
+        const cv::Mat tcw = CurrentFrame.mTcw.rowRange(0, 3).col(3);
+        const int nl = (int)LastFrame.mvpMapPoints.size();
+        std::vector<OrbProbe> probes(nl ? nl : 1);
+        for (int i = 0; i < nl; i++) {
+            OrbProbe& q = probes[i];
+            ClearProbe(q);
+            if (!LastFrame.mvpMapPoints[i]) continue;
+            if (LastFrame.mvbOutlier[i]) continue;
+            cv::Mat x3Dw = LastFrame.mvpMapPoints[i]->GetWorldPos();
+            cv::Mat x3Dc = Rcw * x3Dw + tcw;
+            const float xc = x3Dc.template at<float>(0);
+            const float yc = x3Dc.template at<float>(1);
+            const float invzc = 1.0 / x3Dc.template at<float>(2);
+            float u = FrameT::fx * xc * invzc + FrameT::cx;
+            float v = FrameT::fy * yc * invzc + FrameT::cy;
+            if (u < FrameT::mnMinX || u > FrameT::mnMaxX) continue;
+            if (v < FrameT::mnMinY || v > FrameT::mnMaxY) continue;
+            int nPredictedOctave = LastFrame.mvKeys[i].octave;
+            q.u = u;
+            q.v = v;
+            q.r = th * CurrentFrame.mvScaleFactors[nPredictedOctave];
+            q.min_level = nPredictedOctave - 1;
+            q.max_level = nPredictedOctave + 1;
+            q.angle = LastFrame.mvKeysUn[i].angle;
+            q.valid = 1;
+        }
+        const std::vector<unsigned char> pdesc = packDescriptors(LastFrame), d2 = packDescriptors(CurrentFrame);
+        const int n = (int)CurrentFrame.mvKeysUn.size();
+        std::vector<unsigned char> taken(n ? n : 1);
+        for (int i = 0; i < n; i++) taken[i] = CurrentFrame.mvpMapPoints[i] != 0;
+        const OrbFrameBounds b = {FrameT::mnMinX, FrameT::mnMinY, FrameT::mnMaxX, FrameT::mnMaxY};
+        std::vector<int> owner;
+        const int nmatches =
+            RunProbes(probes, pdesc, nl, CurrentFrame.mvKeysUn, d2, b, taken, ORBHIP_PROJ_BEST, TH_HIGH, mbCheckOrientation, owner);
+        for (int i = 0; i < n; i++)
+            if (owner[i] >= 0) CurrentFrame.mvpMapPoints[i] = LastFrame.mvpMapPoints[owner[i]];
+        return nmatches;
+    }
+
+    // int SearchByProjection(Frame &CurrentFrame, KeyFrame* pKF, const set<MapPoint*> &sAlreadyFound, float th, int ORBdist)
+    // (include/ORBmatcher.h:85, src/ORBmatcher.cc:1633-1757)
+    template <class FrameT, class KeyFrameT, class MapPointT>
+    int SearchByProjection(FrameT& CurrentFrame, KeyFrameT* pKF, const std::set<MapPointT*>& sAlreadyFound, float th, int ORBdist) {
+        const cv::Mat Rcw = CurrentFrame.mTcw.rowRange(0, 3).colRange(0, 3);
+        const cv::Mat tcw = CurrentFrame.mTcw.rowRange(0, 3).col(3);
+        const cv::Mat Ow = -Rcw.t() * tcw;
+        std::vector<MapPointT*> vpMPs = pKF->GetMapPointMatches();
+        const int nk = (int)vpMPs.size();
+        std::vector<OrbProbe> probes(nk ? nk : 1);
+        std::vector<unsigned char> pdesc((size_t)(nk ? nk : 1) * 32);
+        for (int i = 0; i < nk; i++) {
+            OrbProbe& q = probes[i];
+            ClearProbe(q);
+            MapPointT* pMP = vpMPs[i];
+            if (!pMP) continue;
+            if (pMP->isBad() || sAlreadyFound.count(pMP)) continue;
+            cv::Mat x3Dw = pMP->GetWorldPos();
+            cv::Mat x3Dc = Rcw * x3Dw + tcw;
+            const float xc = x3Dc.template at<float>(0);
+            const float yc = x3Dc.template at<float>(1);
+            const float invzc = 1.0 / x3Dc.template at<float>(2);
+            float u = FrameT::fx * xc * invzc + FrameT::cx;
+            float v = FrameT::fy * yc * invzc + FrameT::cy;
+            if (u < FrameT::mnMinX || u > FrameT::mnMaxX) continue;
+            if (v < FrameT::mnMinY || v > FrameT::mnMaxY) continue;
+            float minDistance = pMP->GetMinDistanceInvariance();
+            cv::Mat PO = x3Dw - Ow;
+            float dist3D = cv::norm(PO);
+            float ratio = dist3D / minDistance;
+            std::vector<float>::iterator it =
+                std::lower_bound(CurrentFrame.mvScaleFactors.begin(), CurrentFrame.mvScaleFactors.end(), ratio);
+            const int nPredictedLevel =
+                std::min(static_cast<int>(it - CurrentFrame.mvScaleFactors.begin()), CurrentFrame.mnScaleLevels - 1);
+            q.u = u;
+            q.v = v;
+            q.r = th * CurrentFrame.mvScaleFactors[nPredictedLevel];
+            q.min_level = nPredictedLevel - 1;
+            q.max_level = nPredictedLevel + 1;
+            q.angle = pKF->GetKeyPointUn(i).angle;
+            q.valid = 1;
+            CopyDescriptor(pMP->GetDescriptor(), &pdesc[(size_t)i * 32]);
+        }
+        const std::vector<unsigned char> d2 = packDescriptors(CurrentFrame);
+        const int n = (int)CurrentFrame.mvKeysUn.size();
+        std::vector<unsigned char> taken(n ? n : 1);
+        for (int i = 0; i < n; i++) taken[i] = CurrentFrame.mvpMapPoints[i] != 0;
+        const OrbFrameBounds b = {FrameT::mnMinX, FrameT::mnMinY, FrameT::mnMaxX, FrameT::mnMaxY};
+        std::vector<int> owner;
+        const int nmatches =
+            RunProbes(probes, pdesc, nk, CurrentFrame.mvKeysUn, d2, b, taken, ORBHIP_PROJ_BEST, ORBdist, mbCheckOrientation, owner);
+        for (int i = 0; i < n; i++)
+            if (owner[i] >= 0) CurrentFrame.mvpMapPoints[i] = vpMPs[owner[i]];
+        return nmatches;
+    }
+
+    // ---- SearchByBoW --------------------------------------------------------------------------------
+    // A DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned int>>) flattened in map order.
+    struct FlatFeatureVector {
+        std::vector<int> nodes, start, feat;
+        template <class FeatVecT>
+        explicit FlatFeatureVector(const FeatVecT& fv) {
+            start.push_back(0);
+            for (typename FeatVecT::const_iterator it = fv.begin(); it != fv.end(); ++it) {
+                nodes.push_back((int)it->first);
+                for (size_t k = 0; k < it->second.size(); k++) feat.push_back((int)it->second[k]);
+                start.push_back((int)feat.size());
+            }
+            if (nodes.empty()) nodes.push_back(0);
+            if (feat.empty()) feat.push_back(0);
+        }
+        int count() const { return (int)start.size() - 1; }
+    };
+
+    // int SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches)
+    // (include/ORBmatcher.h:62, src/ORBmatcher.cc:158-295)
+    template <class KeyFrameT, class FrameT, class MapPointT>
+    int SearchByBoW(KeyFrameT* pKF, FrameT& F, std::vector<MapPointT*>& vpMapPointMatches) {
+        std::vector<MapPointT*> vpMapPointsKF = pKF->GetMapPointMatches();
+        vpMapPointMatches = std::vector<MapPointT*>(F.mvpMapPoints.size(), static_cast<MapPointT*>(0));
+        const FlatFeatureVector fvKF(pKF->GetFeatureVector()), fvF(F.mFeatVec);
+        const std::vector<cv::KeyPoint> keysKF = pKF->GetKeyPointsUn();
+        const std::vector<unsigned char> dKF = packRows(pKF->GetDescriptors()), dF = packDescriptors(F);
+        const int nKF = (int)keysKF.size(), nF = (int)F.mvKeys.size();
+        // the .at() of :190-196: a feature index past the keyframe's map points is skipped like a NULL one
+        std::vector<unsigned char> validKF(nKF ? nKF : 1);
+        for (int i = 0; i < nKF; i++)
+            validKF[i] = (size_t)i < vpMapPointsKF.size() && vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad();
+        std::vector<int> m12(nKF ? nKF : 1, -1), m21(nF ? nF : 1, -1);
+        int nmatches = 0;
+        if (orbhip_search_by_bow(handle, (const OrbKeypoint*)keysKF.data(), dKF.data(), nKF, validKF.data(), fvKF.nodes.data(),
+                                 fvKF.start.data(), fvKF.feat.data(), fvKF.count(), (const OrbKeypoint*)F.mvKeys.data(), dF.data(), nF,
+                                 0, fvF.nodes.data(), fvF.start.data(), fvF.feat.data(), fvF.count(), mfNNratio, mbCheckOrientation,
+                                 1, m12.data(), m21.data(), &nmatches) != ORBHIP_OK)
+            throw std::runtime_error(orbhip_last_error());
+        for (int iF = 0; iF < nF; iF++)
+            if (m21[iF] >= 0) vpMapPointMatches[iF] = vpMapPointsKF[m21[iF]];
+        return nmatches;
+    }
+
+    // int SearchByBoW(KeyFrame *pKF1, KeyFrame* pKF2, vector<MapPoint*> &vpMatches12)
+    // (include/ORBmatcher.h:63, src/ORBmatcher.cc:726-861)
+    template <class KeyFrameT, class MapPointT>
+    int SearchByBoW(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<MapPointT*>& vpMatches12) {
+        std::vector<cv::KeyPoint> vKeysUn1 = pKF1->GetKeyPointsUn(), vKeysUn2 = pKF2->GetKeyPointsUn();
+        const FlatFeatureVector fv1(pKF1->GetFeatureVector()), fv2(pKF2->GetFeatureVector());
+        std::vector<MapPointT*> vpMapPoints1 = pKF1->GetMapPointMatches(), vpMapPoints2 = pKF2->GetMapPointMatches();
+        const std::vector<unsigned char> d1 = packRows(pKF1->GetDescriptors()), d2 = packRows(pKF2->GetDescriptors());
+        vpMatches12 = std::vector<MapPointT*>(vpMapPoints1.size(), static_cast<MapPointT*>(0));
+        const int n1 = (int)vKeysUn1.size(), n2 = (int)vKeysUn2.size();
+        std::vector<unsigned char> valid1(n1 ? n1 : 1), valid2(n2 ? n2 : 1);
+        for (int i = 0; i < n1; i++) valid1[i] = vpMapPoints1[i] && !vpMapPoints1[i]->isBad();
+        for (int i = 0; i < n2; i++) valid2[i] = vpMapPoints2[i] && !vpMapPoints2[i]->isBad();
+        std::vector<int> m12(n1 ? n1 : 1, -1), m21(n2 ? n2 : 1, -1);
+        int nmatches = 0;
+        if (orbhip_search_by_bow(handle, (const OrbKeypoint*)vKeysUn1.data(), d1.data(), n1, valid1.data(), fv1.nodes.data(),
+                                 fv1.start.data(), fv1.feat.data(), fv1.count(), (const OrbKeypoint*)vKeysUn2.data(), d2.data(), n2,
+                                 valid2.data(), fv2.nodes.data(), fv2.start.data(), fv2.feat.data(), fv2.count(), mfNNratio,
+                                 mbCheckOrientation, 0, m12.data(), m21.data(), &nmatches) != ORBHIP_OK)
+            throw std::runtime_error(orbhip_last_error());
+        for (int i1 = 0; i1 < n1; i1++)
+            if (m12[i1] >= 0) vpMatches12[i1] = vpMapPoints2[m12[i1]];
+        return nmatches;
+    }
+
+    // ---- the three per-frame / per-map-point steps around the matchers -----------------------------------
+    // MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:191-256): the map point keeps the lines that
+    // collect vDescriptors from its observations (:194-219) and the final mDescriptor = vDescriptors[BestIdx]
+    // .clone() (:252-255); the N x N distances and the median choice (:221-250) are this call.
+    int DistinctiveDescriptorIndex(const std::vector<cv::Mat>& vDescriptors) {
+        const int N = (int)vDescriptors.size();
+        if (N == 0) return -1;
+        std::vector<unsigned char> d((size_t)N * 32);
+        for (int i = 0; i < N; i++) CopyDescriptor(vDescriptors[i], &d[(size_t)i * 32]);
+        const int start[2] = {0, N};
+        int best = -1, median = 0;
+        if (orbhip_distinctive_descriptors(handle, d.data(), start, 1, &best, &median) != ORBHIP_OK)
+            throw std::runtime_error(orbhip_last_error());
+        return best;
+    }
+
+    // Frame::UndistortKeyPoints (src/Frame.cc:290-320): mvKeysUn from mvKeys, mK and mDistCoef.
+    template <class FrameT>
+    void UndistortKeyPoints(FrameT& F) {
+        const OrbCamera cam = {F.mK.template at<float>(0, 0), F.mK.template at<float>(1, 1), F.mK.template at<float>(0, 2),
+                               F.mK.template at<float>(1, 2), F.mDistCoef.template at<float>(0), F.mDistCoef.template at<float>(1),
+                               F.mDistCoef.template at<float>(2), F.mDistCoef.template at<float>(3)};
+        F.mvKeysUn.resize(F.mvKeys.size());
+        if (orbhip_undistort_keypoints(handle, (const OrbKeypoint*)F.mvKeys.data(), (int)F.mvKeys.size(), cam,
+                                       (OrbKeypoint*)F.mvKeysUn.data()) != ORBHIP_OK)
+            throw std::runtime_error(orbhip_last_error());
+    }
+
+    // Frame::ComputeBoW (src/Frame.cc:281-288) for the ORB vocabulary (TF-IDF weights, L1 scoring): the descent of
+    // every descriptor runs on the device, the BowVector / FeatureVector are filled in feature order with the
+    // containers' own addWeight / addFeature (TemplatedVocabulary.h:1150-1163) and normalised as transform() does
+    // (:1193).  l1 is DBoW2::L1.
+    template <class FrameT, class LNormT>
+    void ComputeBoW(FrameT& F, const orbhip_vocabulary* voc, LNormT l1) {
+        if (!F.mBowVec.empty()) return;
+        const int n = F.mDescriptors.rows;
+        const std::vector<unsigned char> d = packDescriptors(F);
+        std::vector<int> word(n ? n : 1), node(n ? n : 1);
+        std::vector<double> weight(n ? n : 1);
+        if (orbhip_bow_transform(handle, voc, d.data(), n, 4, word.data(), node.data(), weight.data()) != ORBHIP_OK)
+            throw std::runtime_error(orbhip_last_error());
+        F.mBowVec.clear();
+        F.mFeatVec.clear();
+        for (int i = 0; i < n; i++)
+            if (weight[i] > 0) {
+                F.mBowVec.addWeight(word[i], weight[i]);
+                F.mFeatVec.addFeature(node[i], i);
+            }
+        F.mBowVec.normalize(l1);
     }
 };
 }  // namespace ORB_SLAM

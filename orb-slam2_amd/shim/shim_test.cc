@@ -4,6 +4,9 @@
 //   shim_test <in.raw> <rows> <cols> <nfeatures> <out.bin>
 #include <cstdio>
 #include <algorithm>
+#include <cstring>
+#include <map>
+#include <set>
 #include <cstdlib>
 #include <ctime>
 #include <string>
@@ -12,26 +15,90 @@
 #include "ORBextractor.h"
 #include "ORBmatcher_accel.h"
 
-// Stand-ins with the members of ORB_SLAM::Frame / MapPoint the forwarding matchers touch.
+// Stand-ins with the members of ORB_SLAM::Frame / KeyFrame / MapPoint and of the DBoW2 containers that the
+// forwarding bodies touch (include/Frame.h, include/KeyFrame.h, include/MapPoint.h,
+// Thirdparty/DBoW2/DBoW2/{BowVector,FeatureVector}.h).
+namespace DBoW2 {
+enum LNorm { L1, L2 };
+struct BowVector : std::map<unsigned int, double> {
+    void addWeight(unsigned int id, double v) {
+        iterator vit = lower_bound(id);
+        if (vit != end() && !(key_comp()(id, vit->first)))
+            vit->second += v;
+        else
+            insert(vit, value_type(id, v));
+    }
+    void normalize(LNorm) {  // L1
+        double norm = 0.0;
+        for (iterator it = begin(); it != end(); ++it) norm += it->second < 0 ? -it->second : it->second;
+        if (norm > 0.0)
+            for (iterator it = begin(); it != end(); ++it) it->second /= norm;
+    }
+};
+struct FeatureVector : std::map<unsigned int, std::vector<unsigned int> > {
+    void addFeature(unsigned int id, unsigned int i_feature) {
+        iterator vit = lower_bound(id);
+        if (vit != end() && vit->first == id)
+            vit->second.push_back(i_feature);
+        else {
+            vit = insert(vit, value_type(id, std::vector<unsigned int>()));
+            vit->second.push_back(i_feature);
+        }
+    }
+};
+}  // namespace DBoW2
+
 struct FakeMapPoint {
     bool bad;
     // tracking fields written by Frame::isInFrustum (include/MapPoint.h)
     bool mbTrackInView;
     int mnTrackScaleLevel;
     float mTrackViewCos, mTrackProjX, mTrackProjY;
-    cv::Mat descriptor;
-    FakeMapPoint() : bad(false), mbTrackInView(false), mnTrackScaleLevel(0), mTrackViewCos(1.f), mTrackProjX(0.f), mTrackProjY(0.f) {}
+    cv::Mat descriptor, pos, normal;
+    float minDist, maxDist;
+    FakeMapPoint()
+        : bad(false), mbTrackInView(false), mnTrackScaleLevel(0), mTrackViewCos(1.f), mTrackProjX(0.f), mTrackProjY(0.f),
+          minDist(0.f), maxDist(0.f) {}
     bool isBad() const { return bad; }
     cv::Mat GetDescriptor() const { return descriptor; }
+    cv::Mat GetWorldPos() const { return pos.clone(); }
+    cv::Mat GetNormal() const { return normal.clone(); }
+    float GetMinDistanceInvariance() const { return minDist; }
+    float GetMaxDistanceInvariance() const { return maxDist; }
 };
 struct FakeFrame {
-    std::vector<cv::KeyPoint> mvKeysUn;
-    cv::Mat mDescriptors;
+    std::vector<cv::KeyPoint> mvKeys, mvKeysUn;
+    cv::Mat mDescriptors, mTcw, mK, mDistCoef;
     std::vector<FakeMapPoint*> mvpMapPoints;
+    std::vector<bool> mvbOutlier;
     std::vector<float> mvScaleFactors;
+    int mnScaleLevels;
+    DBoW2::BowVector mBowVec;
+    DBoW2::FeatureVector mFeatVec;
     static int mnMinX, mnMinY, mnMaxX, mnMaxY;
+    static float fx, fy, cx, cy;
 };
 int FakeFrame::mnMinX, FakeFrame::mnMinY, FakeFrame::mnMaxX, FakeFrame::mnMaxY;
+float FakeFrame::fx, FakeFrame::fy, FakeFrame::cx, FakeFrame::cy;
+struct FakeKeyFrame {
+    float fx, fy, cx, cy;
+    std::vector<cv::KeyPoint> keysUn;
+    cv::Mat descriptors;
+    std::vector<FakeMapPoint*> mapPoints;
+    std::vector<float> scaleFactors;
+    DBoW2::FeatureVector featVec;
+    int GetScaleLevels() const { return (int)scaleFactors.size(); }
+    std::vector<float> GetScaleFactors() const { return scaleFactors; }
+    float GetScaleFactor(int nLevel = 1) const { return scaleFactors[nLevel]; }
+    bool IsInImage(const float& x, const float& y) const {
+        return x >= FakeFrame::mnMinX && x < FakeFrame::mnMaxX && y >= FakeFrame::mnMinY && y < FakeFrame::mnMaxY;
+    }
+    std::vector<cv::KeyPoint> GetKeyPointsUn() const { return keysUn; }
+    cv::KeyPoint GetKeyPointUn(const size_t& idx) const { return keysUn[idx]; }
+    cv::Mat GetDescriptors() { return descriptors.clone(); }
+    std::vector<FakeMapPoint*> GetMapPointMatches() { return mapPoints; }
+    DBoW2::FeatureVector GetFeatureVector() { return featVec; }
+};
 
 // shim_test --latency <in.raw> <rows> <cols> <nfeatures> <calls>: the call of src/Frame.cc:61 repeated on one
 // image, one frame per call as the tracking thread makes it; prints the median, 10th and 90th percentile of the
@@ -61,7 +128,259 @@ static int latency_mode(int argc, char** argv) {
     return 0;
 }
 
+
+// shim_test --matchers <mode> <in.bin> <out.bin>: one forwarding body of shim/ORBmatcher_accel.h on inputs a
+// test wrote, results back for comparison with the oracle.  Both files are sequences of blobs, each an int32
+// byte count followed by the bytes.
+typedef std::vector<std::vector<unsigned char> > Blobs;
+static bool read_blobs(const char* path, Blobs& out) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return false;
+    int nb;
+    while (fread(&nb, 4, 1, f) == 1) {
+        std::vector<unsigned char> b(nb > 0 ? nb : 0);
+        if (nb > 0 && fread(b.data(), 1, nb, f) != (size_t)nb) return false;
+        out.push_back(b);
+    }
+    fclose(f);
+    return true;
+}
+static void write_blob(FILE* f, const void* p, size_t bytes) {
+    int nb = (int)bytes;
+    fwrite(&nb, 4, 1, f);
+    if (bytes) fwrite(p, 1, bytes, f);
+}
+template <class T> static const T* as(const std::vector<unsigned char>& b) { return (const T*)b.data(); }
+static cv::Mat mat_f32(int rows, int cols, const float* src) {
+    cv::Mat m(rows, cols, CV_32F);
+    for (int i = 0; i < rows; i++)
+        for (int j = 0; j < cols; j++) m.at<float>(i, j) = src[i * cols + j];
+    return m;
+}
+static cv::Mat mat_desc(const std::vector<unsigned char>& b) {
+    const int n = (int)(b.size() / 32);
+    cv::Mat m(n, 32, CV_8U);
+    if (n) memcpy(m.data, b.data(), (size_t)n * 32);
+    return m;
+}
+static std::vector<cv::KeyPoint> keypoints(const std::vector<unsigned char>& b) {
+    std::vector<cv::KeyPoint> k(b.size() / sizeof(cv::KeyPoint));
+    if (!k.empty()) memcpy(&k[0], b.data(), k.size() * sizeof(cv::KeyPoint));
+    return k;
+}
+static DBoW2::FeatureVector feature_vector(const std::vector<unsigned char>& nodes, const std::vector<unsigned char>& start,
+                                           const std::vector<unsigned char>& feat) {
+    DBoW2::FeatureVector fv;
+    const int cnt = (int)(nodes.size() / 4);
+    for (int j = 0; j < cnt; j++)
+        for (int k = as<int>(start)[j]; k < as<int>(start)[j + 1]; k++) fv.addFeature(as<int>(nodes)[j], as<int>(feat)[k]);
+    return fv;
+}
+
+static int matchers_mode(int argc, char** argv) {
+    if (argc < 5) return 2;
+    const std::string mode = argv[2];
+    Blobs in;
+    if (!read_blobs(argv[3], in)) return 3;
+    FILE* out = fopen(argv[4], "wb");
+    if (!out) return 3;
+    static FakeMapPoint pre;  // the map point a feature holds on entry
+    if (mode == "sim3" || mode == "frames" || mode == "last" || mode == "keyframe") {
+        // blobs: 0 int params {th, window, orbdist, check_ori}, 1 float params {fx, fy, cx, cy, ratio, th}, 2 bounds,
+        // 3 target keypoints, 4 target descriptors, 5 taken, 6 pose (4x4), 7 scale factors, 8 skip kind per point
+        // (0 = usable, 1 = NULL, 2 = bad, 3 = already found / outlier), 9 positions, 10 normals, 11 min distance,
+        // 12 max distance, 13 point descriptors, 14 source keypoints (one per point)
+        const int* ip = as<int>(in[0]);
+        const float* fp = as<float>(in[1]);
+        const int* bd = as<int>(in[2]);
+        FakeFrame::mnMinX = bd[0]; FakeFrame::mnMinY = bd[1]; FakeFrame::mnMaxX = bd[2]; FakeFrame::mnMaxY = bd[3];
+        FakeFrame::fx = fp[0]; FakeFrame::fy = fp[1]; FakeFrame::cx = fp[2]; FakeFrame::cy = fp[3];
+        ORB_SLAM::ORBmatcherAccel matcher(fp[4], ip[3] != 0);
+        FakeFrame T;  // the target frame
+        T.mvKeysUn = T.mvKeys = keypoints(in[3]);
+        T.mDescriptors = mat_desc(in[4]);
+        const int n = (int)T.mvKeysUn.size();
+        T.mvpMapPoints.assign(n, (FakeMapPoint*)0);
+        for (int i = 0; i < n; i++)
+            if (in[5][i]) T.mvpMapPoints[i] = &pre;
+        T.mTcw = mat_f32(4, 4, as<float>(in[6]));
+        const int nlev = (int)(in[7].size() / 4);
+        T.mvScaleFactors.assign(as<float>(in[7]), as<float>(in[7]) + nlev);
+        T.mnScaleLevels = nlev;
+        const int npts = (int)in[8].size();
+        std::vector<FakeMapPoint> pts(npts);
+        std::vector<FakeMapPoint*> vp(npts);
+        std::set<FakeMapPoint*> found;
+        cv::Mat pdesc = mat_desc(in[13]);
+        for (int i = 0; i < npts; i++) {
+            pts[i].bad = in[8][i] == 2;
+            pts[i].pos = mat_f32(3, 1, as<float>(in[9]) + 3 * i);
+            pts[i].normal = mat_f32(3, 1, as<float>(in[10]) + 3 * i);
+            pts[i].minDist = as<float>(in[11])[i];
+            pts[i].maxDist = as<float>(in[12])[i];
+            pts[i].descriptor = pdesc.row(i);
+            vp[i] = in[8][i] == 1 ? (FakeMapPoint*)0 : &pts[i];
+            if (in[8][i] == 3) found.insert(&pts[i]);
+        }
+        int nmatches = -1;
+        std::vector<FakeMapPoint*> result;
+        if (mode == "sim3") {
+            FakeKeyFrame KF;
+            KF.fx = fp[0]; KF.fy = fp[1]; KF.cx = fp[2]; KF.cy = fp[3];
+            KF.keysUn = T.mvKeysUn;
+            KF.descriptors = T.mDescriptors;
+            KF.scaleFactors = T.mvScaleFactors;
+            // "already found" points of this overload sit in vpMatched on entry: give each one a feature that is taken
+            result = T.mvpMapPoints;
+            std::set<FakeMapPoint*>::iterator it = found.begin();
+            for (int i = 0; i < n && it != found.end(); i++)
+                if (result[i] == &pre) result[i] = *it++;
+            for (int i = 0; i < npts; i++)
+                if (!vp[i]) vp[i] = &pre;  // this overload has no NULL test: a NULL point is modelled as already found
+            nmatches = matcher.SearchByProjection<FakeFrame>(&KF, T.mTcw, vp, result, ip[0]);
+        } else if (mode == "frames") {
+            FakeFrame F1;
+            F1.mvKeysUn = keypoints(in[14]);
+            F1.mDescriptors = pdesc;
+            F1.mvpMapPoints = vp;
+            // an "already found" point is one F2 already holds
+            std::set<FakeMapPoint*>::iterator it = found.begin();
+            for (int i = 0; i < n && it != found.end(); i++)
+                if (T.mvpMapPoints[i] == &pre) T.mvpMapPoints[i] = *it++;
+            nmatches = matcher.SearchByProjection(F1, T, ip[1], result);
+        } else if (mode == "last") {
+            FakeFrame L;
+            L.mvKeys = L.mvKeysUn = keypoints(in[14]);
+            L.mDescriptors = pdesc;
+            L.mvpMapPoints = vp;
+            L.mvbOutlier.assign(npts, false);
+            for (int i = 0; i < npts; i++)
+                if (in[8][i] >= 2) L.mvbOutlier[i] = true;  // kinds 2 and 3 stand for outliers here
+            for (int i = 0; i < npts; i++) pts[i].bad = false;
+            nmatches = matcher.SearchByProjection(T, (const FakeFrame&)L, fp[5]);
+            result = T.mvpMapPoints;
+        } else {
+            FakeKeyFrame KF;
+            KF.keysUn = keypoints(in[14]);
+            KF.mapPoints = vp;
+            nmatches = matcher.SearchByProjection(T, &KF, found, fp[5], ip[2]);
+            result = T.mvpMapPoints;
+        }
+        std::vector<int> owner(n ? n : 1, -1);
+        for (int i = 0; i < n; i++) {
+            FakeMapPoint* q = result[i];
+            if (!q) continue;
+            owner[i] = (q >= &pts[0] && q < &pts[0] + npts) ? (int)(q - &pts[0]) : -2;
+            if (in[5][i]) owner[i] = -2;  // held on entry (by `pre` or by an already-found point)
+        }
+        write_blob(out, &nmatches, 4);
+        write_blob(out, owner.data(), sizeof(int) * n);
+    } else if (mode == "bow_kf_f" || mode == "bow_kf_kf") {
+        // blobs: 0 float {ratio}, 1 int {check_ori}, then per side (2.., 8..): keypoints, descriptors, valid, fv nodes,
+        // fv start, fv features
+        ORB_SLAM::ORBmatcherAccel matcher(as<float>(in[0])[0], as<int>(in[1])[0] != 0);
+        FakeKeyFrame KF[2];
+        std::vector<FakeMapPoint> pts[2];
+        for (int s = 0; s < 2; s++) {
+            const int o = 2 + 6 * s;
+            KF[s].keysUn = keypoints(in[o]);
+            KF[s].descriptors = mat_desc(in[o + 1]);
+            const int n = (int)KF[s].keysUn.size();
+            pts[s].resize(n);
+            KF[s].mapPoints.assign(n, (FakeMapPoint*)0);
+            for (int i = 0; i < n; i++) {
+                const unsigned char v = in[o + 2].empty() ? 1 : in[o + 2][i];  // 1 valid, 0 NULL, 2 bad
+                pts[s][i].bad = v == 2;
+                if (v) KF[s].mapPoints[i] = &pts[s][i];
+            }
+            KF[s].featVec = feature_vector(in[o + 3], in[o + 4], in[o + 5]);
+        }
+        int nmatches;
+        std::vector<FakeMapPoint*> res;
+        std::vector<int> idx;
+        if (mode == "bow_kf_f") {
+            FakeFrame F;
+            F.mvKeys = F.mvKeysUn = KF[1].keysUn;
+            F.mDescriptors = KF[1].descriptors;
+            F.mvpMapPoints.assign(F.mvKeys.size(), (FakeMapPoint*)0);
+            F.mFeatVec = KF[1].featVec;
+            // a keyframe whose map-point vector is shorter than its features (the .at() guard of the reference)
+            if (!KF[0].mapPoints.empty()) KF[0].mapPoints.resize(KF[0].mapPoints.size() - KF[0].mapPoints.size() / 16);
+            nmatches = matcher.SearchByBoW(&KF[0], F, res);
+            idx.assign(res.size() ? res.size() : 1, -1);
+            for (size_t i = 0; i < res.size(); i++)
+                if (res[i]) idx[i] = (int)(res[i] - &pts[0][0]);
+        } else {
+            nmatches = matcher.SearchByBoW(&KF[0], &KF[1], res);
+            idx.assign(res.size() ? res.size() : 1, -1);
+            for (size_t i = 0; i < res.size(); i++)
+                if (res[i]) idx[i] = (int)(res[i] - &pts[1][0]);
+        }
+        write_blob(out, &nmatches, 4);
+        write_blob(out, idx.data(), sizeof(int) * res.size());
+    } else if (mode == "distinct") {
+        ORB_SLAM::ORBmatcherAccel matcher;
+        cv::Mat d = mat_desc(in[0]);
+        std::vector<cv::Mat> v;
+        for (int i = 0; i < d.rows; i++) v.push_back(d.row(i));
+        const int best = matcher.DistinctiveDescriptorIndex(v);
+        write_blob(out, &best, 4);
+    } else if (mode == "undistort") {
+        // blobs: 0 keypoints, 1 float {fx, fy, cx, cy, k1, k2, p1, p2}
+        ORB_SLAM::ORBmatcherAccel matcher;
+        FakeFrame F;
+        F.mvKeys = keypoints(in[0]);
+        const float* c = as<float>(in[1]);
+        const float K[9] = {c[0], 0.f, c[2], 0.f, c[1], c[3], 0.f, 0.f, 1.f};
+        F.mK = mat_f32(3, 3, K);
+        F.mDistCoef = mat_f32(4, 1, c + 4);
+        matcher.UndistortKeyPoints(F);
+        write_blob(out, F.mvKeysUn.empty() ? 0 : &F.mvKeysUn[0], F.mvKeysUn.size() * sizeof(cv::KeyPoint));
+    } else if (mode == "computebow") {
+        // blobs: 0 int {L}, 1 parent, 2 node descriptors, 3 weights (double), 4 frame descriptors
+        ORB_SLAM::ORBmatcherAccel matcher;
+        orbhip_vocabulary* voc = 0;
+        const int nn = (int)(in[1].size() / 4);
+        if (orbhip_vocabulary_create(&voc, 0, nn, as<int>(in[1]), in[2].data(), as<double>(in[3]), as<int>(in[0])[0]) != ORBHIP_OK) {
+            fprintf(stderr, "%s\n", orbhip_last_error());
+            return 7;
+        }
+        FakeFrame F;
+        F.mDescriptors = mat_desc(in[4]);
+        matcher.ComputeBoW(F, voc, DBoW2::L1);
+        orbhip_vocabulary_destroy(voc);
+        std::vector<int> words, nodes, start(1, 0), feat;
+        std::vector<double> vals;
+        for (DBoW2::BowVector::iterator it = F.mBowVec.begin(); it != F.mBowVec.end(); ++it) {
+            words.push_back((int)it->first);
+            vals.push_back(it->second);
+        }
+        for (DBoW2::FeatureVector::iterator it = F.mFeatVec.begin(); it != F.mFeatVec.end(); ++it) {
+            nodes.push_back((int)it->first);
+            for (size_t k = 0; k < it->second.size(); k++) feat.push_back((int)it->second[k]);
+            start.push_back((int)feat.size());
+        }
+        write_blob(out, words.data(), words.size() * 4);
+        write_blob(out, vals.data(), vals.size() * 8);
+        write_blob(out, nodes.data(), nodes.size() * 4);
+        write_blob(out, start.data(), start.size() * 4);
+        write_blob(out, feat.data(), feat.size() * 4);
+    } else {
+        return 2;
+    }
+    fclose(out);
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "--matchers") {
+        try {
+            return matchers_mode(argc, argv);
+        } catch (const std::exception& e) {
+            fprintf(stderr, "%s\n", e.what());
+            return 9;
+        }
+    }
     if (argc > 1 && std::string(argv[1]) == "--latency") return latency_mode(argc, argv);
     if (argc < 6) return 2;
     const int rows = atoi(argv[2]), cols = atoi(argv[3]), nf = atoi(argv[4]);
