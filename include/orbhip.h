@@ -105,6 +105,15 @@ int orbhip_level_geometry(const orbhip_extractor* e, int level, int32_t* out8);
  * stream (milliseconds, whole call). */
 float orbhip_last_elapsed_ms(orbhip_extractor* e);
 
+/* Which build of OpenCV 2.4 the 7x7 Gaussian of src/ORBextractor.cc:760 is reproduced for.  The row pass and
+ * the integer taps are the same in both; the column pass differs only where its sum is an exact tie
+ * (sum mod 2^16 == 2^15): ORBHIP_GAUSS_SCALAR (default, the profile the oracle defines) rounds it up,
+ * (sum + 2^15) >> 16, as the plain C++ column filter does; ORBHIP_GAUSS_SSE2 rounds it to the even neighbour
+ * in the first w & ~3 columns of a level, as the fp32 / cvtps2dq column filter of an SSE2 build does
+ * (about 6 blurred pixels per million and 1 descriptor bit per 2 million differ between the two). */
+#define ORBHIP_GAUSS_SCALAR 0
+#define ORBHIP_GAUSS_SSE2 1
+int orbhip_extractor_set_gaussian_profile(orbhip_extractor* e, int profile);
 /* Per-stage kernel timing (bench instrumentation).  With profiling enabled every extract call
  * brackets its kernel groups with HIP events on the handle's stream; after
  * orbhip_extractor_synchronize, stage_times returns for the last call the summed duration (ms) and

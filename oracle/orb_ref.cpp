@@ -304,6 +304,9 @@ float fast_atan2(float y, float x) {
     return a;
 }
 
+// 0 = scalar column pass (the profile every parity test uses), 1 = SSE2 column pass; see gauss7_roi.
+int g_gauss_profile = 0;
+
 // cv::getGaussianKernel(7, 2, CV_32F) converted to 8-bit fixed point as
 // createSeparableLinearFilter does for CV_8U smoothing kernels (x256, cvRound).
 void gauss_taps(int taps[7]) {
@@ -340,9 +343,28 @@ void gauss7_roi(const unsigned char* in, int w, int h, unsigned char* out, const
             r[x] = acc;
         }
     }
+    // Column pass.  Profile 0 (the oracle's definition): the scalar SymmColumnFilter with FixedPtCastEx,
+    // (sum + 2^15) >> 16.  Profile 1: what an SSE2 build of OpenCV 2.4 runs instead for the first w & ~3
+    // columns (SymmColumnVec_32s8u, modules/imgproc/src/filter.cpp): the taps as float k / 65536, the centre row
+    // times its tap, then for k = 1..3 the integer sum of the two mirrored rows converted to float times its tap,
+    // accumulated in fp32, converted with cvtps2dq (round to nearest even) and saturated; the remaining
+    // w & 3 columns take the scalar path.  Every product and every partial sum below 2^24 / 65536 is exact in
+    // fp32, so the two profiles can only differ where the sum is an exact tie (sum mod 65536 == 32768).
+    const int vec_cols = g_gauss_profile == 1 ? (w & ~3) : 0;
+    float kf[4];
+    for (int k = 0; k < 4; k++) kf[k] = (float)taps[3 + k] * (1.f / 65536.f);
     for (int y = 0; y < h; y++) {
         unsigned char* d = out + (ptrdiff_t)(y + E) * stride + E;
         for (int x = 0; x < w; x++) {
+            if (x < vec_cols) {
+                float s0 = (float)rowsum[(size_t)(y + 3) * w + x] * kf[0] + 0.f;
+                for (int k = 1; k <= 3; k++) {
+                    const int pair = rowsum[(size_t)(y + 3 + k) * w + x] + rowsum[(size_t)(y + 3 - k) * w + x];
+                    s0 = s0 + (float)pair * kf[k];
+                }
+                d[x] = sat_u8((int)std::nearbyint(s0));  // default rounding mode: to nearest even, as cvtps2dq
+                continue;
+            }
             int acc = 0;
             for (int k = 0; k < 7; k++) acc += taps[k] * rowsum[(size_t)(y + k) * w + x];
             d[x] = sat_u8((acc + 32768) >> 16);
@@ -798,6 +820,9 @@ int orbref_nth_prefix(const float* responses, int n, int n_points, int32_t* perm
     for (size_t i = 0; i < v.size(); i++) perm_out[i] = v[i].class_id;
     return (int)v.size();
 }
+
+// Study switch only (tools/sse2_gaussian_divergence.py): never set by the tests or the bench.
+void orbref_set_gauss_profile(int profile) { g_gauss_profile = profile == 1 ? 1 : 0; }
 
 void orbref_gauss7(const uint8_t* padded_in, int w, int h, uint8_t* padded_out) {
     int taps[7];

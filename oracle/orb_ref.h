@@ -81,6 +81,9 @@ int orbref_retain_best(const float* responses, int n, int n_points, int32_t* per
 /* Observable result used by the extractor: first n_points elements after std::nth_element. */
 int orbref_nth_prefix(const float* responses, int n, int n_points, int32_t* perm_out);
 void orbref_gauss7(const uint8_t* padded_in, int w, int h, uint8_t* padded_out);
+/* Study switch of the Gaussian column pass: 0 = scalar (the oracle's profile, the default), 1 = the fp32 /
+ * round-to-even evaluation of an SSE2 build of OpenCV 2.4.  Process-wide; no test or bench sets it. */
+void orbref_set_gauss_profile(int profile);
 float orbref_ic_angle(const uint8_t* center, ptrdiff_t stride);
 void orbref_descriptor(const uint8_t* center, ptrdiff_t stride, float angle_deg, uint8_t* desc32);
 float orbref_cosf(float x);

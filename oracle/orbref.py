@@ -57,6 +57,8 @@ def lib():
         L.orbref_retain_best.argtypes = [vp, i32, i32, vp]
         L.orbref_nth_prefix.argtypes = [vp, i32, i32, vp]
         L.orbref_gauss7.argtypes = [vp, i32, i32, vp]
+        L.orbref_set_gauss_profile.argtypes = [i32]
+        L.orbref_set_gauss_profile.restype = None
         L.orbref_ic_angle.restype = f32
         L.orbref_ic_angle.argtypes = [vp, C.c_ssize_t]
         L.orbref_descriptor.argtypes = [vp, C.c_ssize_t, f32, vp]

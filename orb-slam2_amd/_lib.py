@@ -106,6 +106,7 @@ def lib():
     L.orbhip_valu_rate.argtypes = [vp, i32]
     L.orbhip_valu_rate.restype = C.c_double
     L.orbhip_extractor_set_profiling.argtypes = [vp, i32]
+    L.orbhip_extractor_set_gaussian_profile.argtypes = [vp, i32]
     L.orbhip_extractor_stage_times.argtypes = [vp, vp, vp]
     L.orbhip_selftest.argtypes = [i32, vp, i32, i32, vp]
     L.orbhip_frame_grid_device.argtypes = [vp, vp, vp, i32, i32, OrbFrameBounds, vp, vp]

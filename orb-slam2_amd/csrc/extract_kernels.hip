@@ -687,6 +687,12 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 #define BL_ROWS 32
 #define BL_PREFETCH 8
 
+// TIE_EVEN selects how an exact tie of the column pass (sum mod 2^16 == 2^15) rounds in the first w & ~3 ROI
+// columns: false = half up, (sum + 2^15) >> 16, the scalar column filter of OpenCV 2.4; true = to the even
+// neighbour, which is what the fp32 + cvtps2dq column filter of an SSE2 build (SymmColumnVec_32s8u) produces
+// there — every product and partial sum of that filter is exact in fp32 below saturation, so ties are the only
+// difference.
+template <bool TIE_EVEN>
 __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
                                               const GeomDev* __restrict__ g, int level, int t0, int t1, int t2, int t3) {
     const LevelGeom& L = g->lv[level];
@@ -762,6 +768,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
                                 a += (uint32_t)t0 * (h[(i - 6) % 7][j] + h[i % 7][j]);
                                 a += (uint32_t)t1 * (h[(i - 5) % 7][j] + h[(i - 1) % 7][j]);
                                 a += (uint32_t)t2 * (h[(i - 4) % 7][j] + h[(i - 2) % 7][j]);
+                                if (TIE_EVEN && px0 + j - ORB_EDGE < (L.w & ~3) && (a & 0xffffu) == 0u) a &= ~0x10000u;
                                 acc[j] = min(a, 0xffffffu);
                             }
                             const uint32_t bl = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u) |
@@ -1063,10 +1070,13 @@ void launch_harris_select(hipStream_t st, const GeomDev& hg, int batch, const ui
 }
 
 void launch_blur(hipStream_t st, const GeomDev& hg, int batch, int level, const uint8_t* pyr, uint8_t* blur,
-                 const GeomDev* dg, const int taps[7]) {
+                 const GeomDev* dg, const int taps[7], bool tie_even) {
     const LevelGeom& L = hg.lv[level];
     dim3 grid((L.stride / 4 + 63) / 64, (L.ph + 4 * BL_ROWS - 1) / (4 * BL_ROWS), batch), block(64, 4);
-    hipLaunchKernelGGL(k_blur, grid, block, 0, st, pyr, blur, dg, level, taps[0], taps[1], taps[2], taps[3]);
+    if (tie_even)
+        hipLaunchKernelGGL(k_blur<true>, grid, block, 0, st, pyr, blur, dg, level, taps[0], taps[1], taps[2], taps[3]);
+    else
+        hipLaunchKernelGGL(k_blur<false>, grid, block, 0, st, pyr, blur, dg, level, taps[0], taps[1], taps[2], taps[3]);
 }
 
 void launch_orient_describe(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* pyr, const uint8_t* blur,

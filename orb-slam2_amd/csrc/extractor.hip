@@ -94,6 +94,7 @@ struct orbhip_extractor {
     int max_batch;
     // per-stage timing (bench instrumentation): events bracket each kernel group of a chunk
     bool profiling = false;
+    bool gauss_tie_even = false;  // ORBHIP_GAUSS_SSE2: ties of the Gaussian column pass round to even
     std::vector<hipEvent_t> prof_ev;           // (ORB_NSTAGES + 1) events per chunk of the last call
     int prof_chunks = 0;
     float stage_ms[ORB_NSTAGES] = {0};
@@ -410,7 +411,7 @@ int run_chunk(orbhip_extractor* e, hipStream_t st, int slot0, const uint8_t* d_i
         orbk::launch_select(st, g, batch, dg, e->d_cells.as<CellDesc>(), cand, ntotal, nretain, lvl, lvlcount, e->d_err.as<int>());
     STAGE_MARK(5);
     STAGE_MARK(6);  // the orientation is computed by the descriptor kernel
-    for (int l = 0; l < g.nlevels; l++) orbk::launch_blur(st, g, batch, l, pyr, blur, dg, e->gtaps);
+    for (int l = 0; l < g.nlevels; l++) orbk::launch_blur(st, g, batch, l, pyr, blur, dg, e->gtaps, e->gauss_tie_even);
     STAGE_MARK(7);
     orbk::launch_orient_describe(st, g, batch, pyr, blur, dg, lvl, key_words, lvlcount, e->d_disc.as<uint32_t>(), angles,
                                  e->d_pattern.as<int8_t>(), e->d_slots.as<uint8_t>() + (size_t)slot0 * g.nfeatures * orbk::slot_record_bytes(),
@@ -635,6 +636,13 @@ static int wait_and_collect_times(orbhip_extractor* e) {
 int orbhip_extractor_synchronize(orbhip_extractor* e) {
     const int rc = wait_and_collect_times(e);
     return rc ? rc : check_device_error(e);
+}
+
+int orbhip_extractor_set_gaussian_profile(orbhip_extractor* e, int profile) {
+    if (!e) return orb_fail(ORBHIP_EINVAL, "null extractor");
+    if (profile != ORBHIP_GAUSS_SCALAR && profile != ORBHIP_GAUSS_SSE2) return orb_fail(ORBHIP_EINVAL, "unknown profile %d", profile);
+    e->gauss_tie_even = profile == ORBHIP_GAUSS_SSE2;
+    return ORBHIP_OK;
 }
 
 int orbhip_extractor_set_profiling(orbhip_extractor* e, int enable) {

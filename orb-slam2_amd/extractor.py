@@ -89,6 +89,13 @@ class ORBextractor:
         _lib.check(self._L.orbhip_extract_batch_device(self._h, d_imgs, batch, rows, cols, row_stride, frame_stride,
                                                        d_kp, d_desc, cap, d_n))
 
+    GAUSS_SCALAR, GAUSS_SSE2 = 0, 1
+
+    def set_gaussian_profile(self, profile):
+        """Column-pass rounding of the 7x7 Gaussian: GAUSS_SCALAR (default, the oracle's profile) or GAUSS_SSE2
+        (ties to even in the first w & ~3 columns, as an SSE2 build of OpenCV 2.4 rounds them)."""
+        _lib.check(self._L.orbhip_extractor_set_gaussian_profile(self._h, int(profile)))
+
     def synchronize(self):
         _lib.check(self._L.orbhip_extractor_synchronize(self._h))
 

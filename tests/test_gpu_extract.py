@@ -298,3 +298,39 @@ def test_dense_corner_images(orb, orbref, kind, nf, th, score):
     dkp, ddesc = dev(img)
     _assert_same(rkp, rdesc, dkp, ddesc)
     assert len(rkp) > 500
+
+
+def test_sse2_gaussian_profile(orb, orbref, synth):
+    """ORBHIP_GAUSS_SSE2: blurred planes and descriptors equal the oracle's SSE2 study profile (ties of the column
+    pass to even in the first w & ~3 columns); on an image of few grey levels the two profiles really differ."""
+    img = synth.synth_image(322, 240, 9)
+    # 7-pixel patterns whose tap-weighted sum is 2^15, repeated down columns and along rows: exact ties of the
+    # column pass at level 0, also in the last w & 3 columns where both profiles round up
+    pats = ([222, 234, 88, 14, 216, 98, 101], [121, 88, 226, 16, 194, 81, 188], [18, 201, 141, 159, 86, 90, 149])
+    for i, x0 in enumerate(range(12, 300, 37)):
+        img[i * 9:i * 9 + 150, x0:x0 + 7] = np.array(pats[i % 3], np.uint8)[None, :]
+    img[200:207, 30:] = np.array(pats[1], np.uint8)[:, None]
+    ext = orb.ORBextractor(500, 1.2, 8, 1, 20, max_width=322, max_height=240)
+    ref = orbref.RefExtractor(500, 1.2, 8, 1, 20)
+    kp0, d0 = ext(img)
+    ext.set_gaussian_profile(ext.GAUSS_SSE2)
+    kp1, d1 = ext(img)
+    dev_planes = [ext.tap_plane(1, 0, l) for l in range(8)]
+    orbref.lib().orbref_set_gauss_profile(1)
+    try:
+        rkp, rd = ref(img)
+        ref_planes = [ref.plane(l, blurred=True).copy() for l in range(8)]
+    finally:
+        orbref.lib().orbref_set_gauss_profile(0)
+    rkp0, rd0 = ref(img)
+    scalar_planes = [ref.plane(l, blurred=True).copy() for l in range(8)]
+    assert np.array_equal(kp0.view(np.uint32), rkp0.view(np.uint32)) and np.array_equal(d0, rd0)
+    assert np.array_equal(kp1.view(np.uint32), rkp.view(np.uint32)) and np.array_equal(d1, rd)
+    for a, b in zip(dev_planes, ref_planes):
+        assert np.array_equal(a, b)
+    assert sum(int((a != b).sum()) for a, b in zip(ref_planes, scalar_planes)) > 10
+    ext.set_gaussian_profile(ext.GAUSS_SCALAR)
+    kp2, d2 = ext(img)
+    assert np.array_equal(d2, d0)
+    with pytest.raises(orb.OrbhipError):
+        ext.set_gaussian_profile(7)

@@ -264,3 +264,43 @@ def test_empty_and_tiny_images(orbref):
         e(np.zeros((40, 40), np.uint8))
     kp, desc = e(np.full((480, 640), 9, np.uint8))
     assert len(kp) == 0 and desc.shape == (0, 32)
+
+
+def test_sse2_gaussian_profile_differs_from_the_scalar_one_only_on_exact_ties(orbref):
+    """The study profile of the Gaussian column pass (fp32 accumulation, round to nearest even, first w & ~3
+    columns) against the scalar profile on planes built to hit ties: the outputs may differ only where the
+    integer column sum is an exact tie, there by one grey level towards the even value, and never in the last
+    w & 3 columns.  The integer sums are recomputed here from the taps."""
+    rng = np.random.default_rng(12)
+    taps = np.array([18, 34, 49, 55, 49, 34, 18], np.int64)
+    L = orbref.lib()
+    ties = diffs = 0
+    for w, h in ((67, 41), (130, 37), (64, 64)):
+        # exact ties are planted: a 7-pixel pattern whose tap-weighted sum is 2^15, repeated down a column
+        # (constant columns multiply the row sum by 257, which keeps the tie) or along a row (ties in every
+        # column of that row, the last w & 3 included)
+        plane = rng.integers(0, 256, (h + 32, w + 32)).astype(np.uint8)
+        pats = ([222, 234, 88, 14, 216, 98, 101], [121, 88, 226, 16, 194, 81, 188], [18, 201, 141, 159, 86, 90, 149])
+        for i, x0 in enumerate((20, 31, 16 + w - 8)):
+            plane[:, x0:x0 + 7] = np.array(pats[i], np.uint8)[None, :]
+        plane[22:29, :] = np.array(pats[1], np.uint8)[:, None]
+        o0 = np.zeros_like(plane)
+        o1 = np.zeros_like(plane)
+        L.orbref_gauss7(plane.ctypes.data, w, h, o0.ctypes.data)
+        L.orbref_set_gauss_profile(1)
+        try:
+            L.orbref_gauss7(plane.ctypes.data, w, h, o1.ctypes.data)
+        finally:
+            L.orbref_set_gauss_profile(0)
+        p = plane.astype(np.int64)
+        rows = sum(taps[k] * p[:, 13 + k:13 + k + w] for k in range(7))          # all rows, ROI columns
+        col = sum(taps[k] * rows[13 + k:13 + k + h] for k in range(7))            # ROI rows
+        assert np.array_equal(o0[16:16 + h, 16:16 + w], np.minimum((col + 32768) >> 16, 255))
+        tie = (col % 65536) == 32768
+        tie[:, (w & ~3):] = False
+        even = np.minimum(np.where(tie & (((col + 32768) >> 16) % 2 == 1), ((col + 32768) >> 16) - 1, (col + 32768) >> 16), 255)
+        assert np.array_equal(o1[16:16 + h, 16:16 + w], even)
+        assert np.array_equal(o1[:16], plane[:16]) and np.array_equal(o1[:, :16], plane[:, :16])
+        ties += int(tie.sum())
+        diffs += int((o0 != o1).sum())
+    assert ties > 20 and 0 < diffs <= ties
