@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liborbhip.so")
+# ORBHIP_LIBRARY names another build of the same library (developer builds with instrumentation)
+LIB_PATH = os.environ.get("ORBHIP_LIBRARY") or os.path.join(_HERE, "liborbhip.so")
 
 OK, EINVAL, ENOMEM, EHIP, ECAP, EGEOM, ENODEV, EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7
 

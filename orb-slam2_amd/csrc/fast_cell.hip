@@ -35,6 +35,22 @@ namespace orbk {
 #define FC_WCAP (2 * 256 + 64)  // per-wave list: survivors of two rows + a carried-over partial chunk
 #define FC_QCAP (FC_WAVES * FC_WCAP)
 
+// Developer instrumentation (-DORBHIP_FC_PHASE_TIMING, never in a shipped build): shader-clock cycles every
+// wave spends in each phase of k_fast_cell, summed over waves; read and reset through orbhip_debug_fc_phase.
+#ifdef ORBHIP_FC_PHASE_TIMING
+__device__ unsigned long long fc_phase[8];
+#define FC_T0 unsigned long long tprev_ = __builtin_readcyclecounter();
+#define FC_T(k)                                                              \
+    {                                                                        \
+        const unsigned long long now_ = __builtin_readcyclecounter();        \
+        if (lane == 0) atomicAdd(&fc_phase[k], now_ - tprev_);               \
+        tprev_ = now_;                                                       \
+    }
+#else
+#define FC_T0
+#define FC_T(k)
+#endif
+
 __device__ __forceinline__ int lane_prefix(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
 }
@@ -66,10 +82,8 @@ __device__ __forceinline__ uint32_t nb_max8(const uint8_t* __restrict__ p, int s
 // BT - I says "I is not brighter than v + t"; with DK = 0x8000 + v - t - 1, bit 15 of DK - I says "I is
 // darker than v - t".  No field ever borrows from its neighbour (every difference stays within
 // 0x8000 +- 511).  A pixel passes iff (up or down) and (left or right) are brighter, or the same with
-// darker.  Returns the four pass bits of the group (bit j = pixel j).
-__device__ __forceinline__ uint32_t quick_row_swar(const uint8_t* __restrict__ imgb, int pitch, int gg, int r, uint32_t T0,
-                                                   uint32_t T1) {
-    const uint32_t* row = (const uint32_t*)(imgb + (r + 3) * pitch) + gg;
+// darker.  row points at the group's dword in its tile row.  Returns the four pass bits of the group (bit j = pixel j).
+__device__ __forceinline__ uint32_t quick_row_swar(const uint32_t* __restrict__ row, int pitch, uint32_t T0, uint32_t T1) {
     const uint32_t wl = row[-1], wm = row[0], wr = row[1];
     const uint32_t up = *(const uint32_t*)((const uint8_t*)row - 3 * pitch);
     const uint32_t dn = *(const uint32_t*)((const uint8_t*)row + 3 * pitch);
@@ -98,7 +112,11 @@ __device__ __forceinline__ uint32_t quick_row_swar(const uint8_t* __restrict__ i
     return (x | (x >> 14)) & 0xfu;
 }
 
-__global__ __launch_bounds__(FC_THREADS) void k_fast_cell(const uint8_t* __restrict__ pyr, const GeomDev* __restrict__ g,
+// WPS = waves per SIMD the register allocation aims at: the workgroups a CU holds are limited by their LDS
+// (cell size), and the register budget follows from that number (8 waves per SIMD = 64 VGPRs for the small
+// cells of which four workgroups fit, 6 = 80 VGPRs for the large ones of which three fit).
+template <int WPS>
+__global__ __launch_bounds__(FC_THREADS) __attribute__((amdgpu_waves_per_eu(WPS, WPS))) void k_fast_cell(const uint8_t* __restrict__ pyr, const GeomDev* __restrict__ g,
                                                           const CellDesc* __restrict__ cells, uint32_t* __restrict__ cand,
                                                           int* __restrict__ n_total, int* __restrict__ err, int ccap) {
     extern __shared__ uint4 lds4[];
@@ -113,6 +131,7 @@ __global__ __launch_bounds__(FC_THREADS) void k_fast_cell(const uint8_t* __restr
         if (tid == 0) *out_total = 0;
         return;
     }
+    FC_T0
     const LevelGeom& L = g->lv[cd.level];
     const int stride = L.stride;
     const uint8_t* plane = pyr + (long long)f * g->frame_bytes + L.plane_off;
@@ -157,16 +176,23 @@ __global__ __launch_bounds__(FC_THREADS) void k_fast_cell(const uint8_t* __restr
         }
     }
 
+    FC_T(0)
     const int tHi = min(max(g->fast_th, 0), 255), tLo = 7;
     const int c_lo = shift + 3;  // examined tile columns [c_lo, c_lo + cw)
     const int g_first = c_lo >> 2;
-    const int gg = g_first + lane;  // this lane's 4-pixel group (tile columns 4gg .. 4gg+3)
-    const bool act = 4 * gg < c_lo + cw;
-    // bit j set: pixel j of this lane's group is an examined pixel
-    uint32_t vnib = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-        if (act && 4 * gg + j >= c_lo && 4 * gg + j < c_lo + cw) vnib |= 1u << j;
+    // A row of the cell is ngroups 4-pixel groups wide; the groups of the cell, row after row, form one sequence
+    // that is cut into chunks of 64, one group per lane, so that every lane has work whatever the cell's width.
+    // A wave takes chunk (8 it + wave) of the first half of the sequence and the corresponding chunk of the
+    // second half in iteration it (two chunks per prefix sum); a lane's (row, group) advances by 512 groups per
+    // iteration with the quotient and remainder of 512 / ngroups, which are wave-uniform.
+    const int ngroups = ((c_lo + cw + 3) >> 2) - g_first;
+    const int nchunks = (ngroups * ch + 63) >> 6;
+    const int iters = (nchunks + 2 * FC_WAVES - 1) / (2 * FC_WAVES);
+    const int dr = (64 * FC_WAVES) / ngroups, dg = 64 * FC_WAVES - dr * ngroups;
+    const int step_addr = dr * pitch + 4 * dg, wrap_addr = pitch - 4 * ngroups;
+    // pixels of the first / last group of a row that lie outside the examined columns
+    const uint32_t lowbits = (1u << (c_lo & 3)) - 1u;
+    const uint32_t highbits = 0xfu & ~((1u << (c_lo + cw - 4 * (g_first + ngroups - 1))) - 1u);
     uint32_t* out = cand + (long long)f * g->cand_per_frame + cd.cand_off;
 
     for (int pass = 0; pass < 2; pass++) {
@@ -178,6 +204,7 @@ __global__ __launch_bounds__(FC_THREADS) void k_fast_cell(const uint8_t* __restr
         if (tid == 0) cn = 0;
     }
     __syncthreads();
+    FC_T(1)
     const uint32_t T0 = (uint32_t)t * 0x00010001u, T1 = T0 + 0x00010001u;
 
     // ---- quick test + exact measure: every wave works through its own rows and its own list, no
@@ -186,14 +213,33 @@ __global__ __launch_bounds__(FC_THREADS) void k_fast_cell(const uint8_t* __restr
     // measure always runs with all lanes busy; what is left (< 64 entries) waits for the next rows.
     uint16_t* wl = qlist + wave * FC_WCAP;
     int n = 0;
-    for (int ra = 2 * wave; ra < ch; ra += 2 * FC_WAVES) {
-        const int rb2 = ra + 1;
+    // per-lane position in the two halves of the group sequence
+    int rowA, glA, rowB, glB;
+    {
+        const int iA = (wave << 6) + lane, iB = ((FC_WAVES * iters + wave) << 6) + lane;
+        rowA = iA / ngroups;
+        glA = iA - rowA * ngroups;
+        rowB = iB / ngroups;
+        glB = iB - rowB * ngroups;
+    }
+    int adrA = (rowA + 3) * pitch + 4 * (g_first + glA), adrB = (rowB + 3) * pitch + 4 * (g_first + glB);
+#define FC_VNIB(gl) (0xfu ^ (lowbits & (uint32_t)(((gl)-1) >> 31)) ^ (highbits & (uint32_t)((ngroups - 2 - (gl)) >> 31)))
+#define FC_ADVANCE(row, gl, adr)                                   \
+    {                                                              \
+        const int t_ = (gl) + dg - ngroups, m_ = t_ >> 31;         \
+        gl = t_ + (ngroups & m_);                                  \
+        row += dr + 1 + m_;                                        \
+        adr += step_addr + (wrap_addr & ~m_);                      \
+    }
+    for (int it = 0; it < iters; it++) {
+        const bool haveB = __builtin_amdgcn_readfirstlane(rowB) < ch;  // lane 0 holds the chunk's first group
         // per-lane pass nibbles (bit j = pixel j of the group passes and is an examined pixel)
         uint32_t nibA = 0, nibB = 0;
-        if (act) nibA = quick_row_swar(imgb, pitch, gg, ra, T0, T1) & vnib;
-        if (act && rb2 < ch) nibB = quick_row_swar(imgb, pitch, gg, rb2, T0, T1) & vnib;
-        // every lane appends its own survivors as one run per row: positions from one wave-wide prefix
-        // sum of the per-lane counts (both rows packed in one register); each row stays in raster order
+        if (rowA < ch) nibA = quick_row_swar((const uint32_t*)(imgb + adrA), pitch, T0, T1) & FC_VNIB(glA);
+        if (haveB && rowB < ch) nibB = quick_row_swar((const uint32_t*)(imgb + adrB), pitch, T0, T1) & FC_VNIB(glB);
+        // every lane appends its own survivors as one run per chunk: positions from one wave-wide prefix sum
+        // of the per-lane counts (both chunks packed in one register).  The order of a wave's list does not
+        // matter: the bitmap restores raster order.
         const uint32_t cnt = (uint32_t)__popc(nibA) | ((uint32_t)__popc(nibB) << 16);
         const uint32_t incl = wave_inclusive_sum(cnt);
         const uint32_t excl = incl - cnt;
@@ -201,21 +247,24 @@ __global__ __launch_bounds__(FC_THREADS) void k_fast_cell(const uint8_t* __restr
         const int totA = (int)(tot & 0xffffu), totB = (int)(tot >> 16);
         {
             int pos = n + (int)(excl & 0xffffu);
-            const uint32_t e = (uint32_t)(ra << 8) | (uint32_t)(4 * gg);
+            const uint32_t e = (uint32_t)(rowA << 8) | (uint32_t)(4 * (g_first + glA));
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 if ((nibA >> j) & 1u) wl[pos++] = (uint16_t)(e + j);
         }
-        {
+        if (haveB) {
             int pos = n + totA + (int)(excl >> 16);
-            const uint32_t e = (uint32_t)(rb2 << 8) | (uint32_t)(4 * gg);
+            const uint32_t e = (uint32_t)(rowB << 8) | (uint32_t)(4 * (g_first + glB));
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 if ((nibB >> j) & 1u) wl[pos++] = (uint16_t)(e + j);
         }
+        FC_ADVANCE(rowA, glA, adrA);
+        FC_ADVANCE(rowB, glB, adrB);
         n += totA + totB;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const bool last = ra + 2 * FC_WAVES >= ch;
+        FC_T(2)
+        const bool last = it + 1 == iters;
         while (n >= 64 || (last && n > 0)) {
             const int i = n - 64 + lane;  // the last (partial) chunk leaves the low lanes idle
             uint32_t e = 0;
@@ -236,8 +285,12 @@ __global__ __launch_bounds__(FC_THREADS) void k_fast_cell(const uint8_t* __restr
             }
             n = max(n - 64, 0);
         }
+        FC_T(3)
     }
+#undef FC_VNIB
+#undef FC_ADVANCE
     __syncthreads();
+    FC_T(4)
 
     // ---- strict-maximum NMS into the bitmap --------------------------------------------------------
     const int ncorner = cn;
@@ -258,6 +311,7 @@ __global__ __launch_bounds__(FC_THREADS) void k_fast_cell(const uint8_t* __restr
         }
     }
     __syncthreads();
+    FC_T(5)
 
     // ---- count, then raster-ordered output --------------------------------------------------------
     const int per = (nwords + FC_THREADS - 1) / FC_THREADS;
@@ -278,6 +332,7 @@ __global__ __launch_bounds__(FC_THREADS) void k_fast_cell(const uint8_t* __restr
         if (w < wave) off += red[w];
         total += red[w];
     }
+    FC_T(6)
     // "if(cellKeyPoints[i][j].size()<=3)" -> clear and FAST(cellImage, ..., 7, true)
     if (pass == 0 && total <= 3) {
         __syncthreads();
@@ -304,6 +359,7 @@ __global__ __launch_bounds__(FC_THREADS) void k_fast_cell(const uint8_t* __restr
         }
     }
     if (tid == 0) *out_total = total;
+    FC_T(7)
     break;
     }  // pass
 }
@@ -337,7 +393,19 @@ void launch_fast_cell(hipStream_t st, const GeomDev& hg, int batch, int max_cw, 
     const int ccap = corner_list_cap();
     const size_t lds = fast_cell_lds_bytes(max_cw, max_ch, ccap);
     dim3 grid(hg.cells_per_frame, batch), block(FC_THREADS);
-    hipLaunchKernelGGL(k_fast_cell, grid, block, lds, st, pyr, dg, cells, cand, n_total, err, ccap);
+    // four workgroups per CU need <= 40 KB each and 8 waves per SIMD
+    if (lds <= 40 * 1024)
+        hipLaunchKernelGGL(k_fast_cell<8>, grid, block, lds, st, pyr, dg, cells, cand, n_total, err, ccap);
+    else
+        hipLaunchKernelGGL(k_fast_cell<6>, grid, block, lds, st, pyr, dg, cells, cand, n_total, err, ccap);
 }
 
 }  // namespace orbk
+
+#ifdef ORBHIP_FC_PHASE_TIMING
+extern "C" int orbhip_debug_fc_phase(unsigned long long* out8) {
+    unsigned long long z[8] = {0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(orbk::fc_phase), sizeof(z)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(orbk::fc_phase), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
