@@ -6,8 +6,10 @@
 One "step" is one pass of the extractor (pyramid, cell-grid FAST, selection, orientation, blur,
 rotated-BRIEF descriptors, keypoint records) over one batch of synthetic frames that is already
 resident in HBM.  The workload is the configuration the headline metric is quoted on: 640x480 frames,
-1000 features per frame (8 levels, scale 1.2), 256 frames per GPU and step.  With N > 1 (one process
-per GPU, launched by torch.distributed.run) every rank processes its own batch of 256 frames: frames
+1000 features per frame (8 levels, scale 1.2), 1024 frames per GPU and step (the rate grows with the
+batch until the short launches of the upper pyramid levels are amortised: 181 k / 210 k / 227 k / 234 k frames/s at
+128 / 256 / 512 / 1024 frames).  With N > 1 (one process
+per GPU, launched by torch.distributed.run) every rank processes its own batch of 1024 frames: frames
 are independent, so the path is sharded by frame batch with no data-path collective (weak scaling);
 the only collectives of the timed region are the timing barrier and a MAX over ranks of the elapsed time.
 
@@ -232,7 +234,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=1024, help="frames per GPU per step")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--features", type=int, default=1000)
@@ -839,6 +841,33 @@ def windowed_leg(orb, torch, dev, orbref):
                                            hd1[f, :k], np.zeros(k, np.uint8), pos, 15.0, True)
         t_p += time.perf_counter() - t0
         ok = ok and np.array_equal(rmo, mo[f, :k]) and rn == int(nm_p[f].item())
+    # extraction -> grid -> SearchByProjection of the whole batch: every call blocking (the default) against the
+    # same calls queued behind a candidate reservation with one synchronisation at the end
+    mq = orb.ORBmatcher(0.9, True, device=dev)
+    mq.reserve_candidates(64 << 20)
+
+    def chain(mm):
+        Fc = orb.FrameBatch.from_images(wl.ext, mm, wl.d_img)
+        return mm.SearchByProjection(Fc, probes, d1, n, orb.ORBmatcher.PROJ_BEST, th_dist=100)
+
+    res_chain = {}
+    for name, mm in (("blocking", m_proj), ("queued", mq)):
+        chain(mm)
+        mm.synchronize()
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            nmc, moc = chain(mm)
+            mm.synchronize()
+            wl.ext.synchronize()
+            torch.cuda.synchronize(dev)
+            ts.append(time.perf_counter() - t0)
+        res_chain[name] = (float(np.median(ts)), nmc, moc)
+    out["extract_grid_project_chain"] = {
+        "frames": b, "blocking_ms": round(res_chain["blocking"][0] * 1e3, 3), "queued_ms": round(res_chain["queued"][0] * 1e3, 3),
+        "queued_frames_per_sec": round(b / res_chain["queued"][0], 1),
+        "same_result": bool(torch.equal(res_chain["blocking"][2], res_chain["queued"][2]))}
     out["frame_grid_ms_per_%d_frames" % b] = round(t_grid * 1e3, 3)
     out["cpu_oracle_1_thread_pairs_per_sec"] = {"search_for_initialization_w100": round(4 / t_i, 1),
                                                 "window_search_w100": round(4 / t_w, 1),

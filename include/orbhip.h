@@ -251,13 +251,24 @@ int orbhip_features_in_area_device(orbhip_matcher* m, const OrbKeypoint* d_kp, c
                                    const OrbAreaQuery* d_queries, int nq, int32_t* d_out_start, int32_t* d_out,
                                    int out_cap);
 
+/* Asynchronous form of the windowed and projection matchers below (orbhip_search_for_initialization_device,
+ * orbhip_window_search_device, orbhip_search_by_projection_device).  Their candidate lists (one 4-byte record per
+ * feature that a GetFeaturesInArea call returns) live in a workspace of the handle.  Without a reservation
+ * (entries = 0, the default) each call sizes that workspace from a count it reads back from the device, and
+ * blocks.  With a reservation of `entries` records the calls read nothing back and return as soon as their
+ * kernels are queued on the matcher's stream; a call whose lists need more than the reservation produces no
+ * matches (all -1, counts 0) and makes the next orbhip_matcher_synchronize fail with ORBHIP_ECAP, the message
+ * naming the count that was needed.  No counterpart in the reference (its matchers are host loops). */
+int orbhip_matcher_reserve_candidates(orbhip_matcher* m, long long entries);
+
 /* Replaces ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:609-724) for `batch` independent
  * frame pairs (F1 = *_1, F2 = *_2 with its grid).  d_prev_matched (batch*cap*2 floats, x then y) is
  * vbPrevMatched: read as the window centres and updated for the matched keypoints.  Outputs
  * d_matches12 (batch*cap, vnMatches12: index in F2 or -1) and d_nmatches (batch).  The sequential
  * dependence of the reference (a later keypoint of F1 can take a feature of F2 away from an
  * earlier one, rotation histogram over every accepted match) is reproduced exactly.
- * Blocking: sizes an internal workspace from a device count. */
+ * Blocking (sizes an internal workspace from a device count) unless a reservation is in place
+ * (orbhip_matcher_reserve_candidates). */
 int orbhip_search_for_initialization_device(orbhip_matcher* m, const OrbKeypoint* d_kp1, const uint8_t* d_desc1,
                                             const int32_t* d_n1, const OrbKeypoint* d_kp2, const uint8_t* d_desc2,
                                             const int32_t* d_n2, const int32_t* d_cell_start2,
@@ -269,7 +280,7 @@ int orbhip_search_for_initialization_device(orbhip_matcher* m, const OrbKeypoint
  * for "F1.mvpMapPoints[i] exists and is not bad"; min_level <= 0 and max_level == INT_MAX switch
  * the level filters off as in the reference.  Output d_matches21 (batch*cap): the F1 index whose
  * map point is assigned to each F2 feature (vpMapPointMatches2[i2] = F1.mvpMapPoints[that]) or -1;
- * d_nmatches (batch).  Blocking, as above. */
+ * d_nmatches (batch).  Blocking unless a reservation is in place, as above. */
 int orbhip_window_search_device(orbhip_matcher* m, const OrbKeypoint* d_kp1, const uint8_t* d_desc1,
                                 const int32_t* d_n1, const uint8_t* d_valid1, const OrbKeypoint* d_kp2,
                                 const uint8_t* d_desc2, const int32_t* d_n2, const int32_t* d_cell_start2,
@@ -303,7 +314,7 @@ typedef struct OrbProbe {
  * check_orientation != 0 the rotation histogram / three-maxima filter over the new matches.
  * Output d_match_of_feature (batch*cap): the probe assigned to each feature by this call or -1;
  * d_nmatches (batch).  probe_cap <= ORBHIP_MAX_PROBES.  Blocking (sizes a workspace from a device
- * count). */
+ * count) unless a reservation is in place. */
 int orbhip_search_by_projection_device(orbhip_matcher* m, const OrbProbe* d_probes, const uint8_t* d_probe_desc,
                                        const int32_t* d_nprobes, int probe_cap, const OrbKeypoint* d_kp2,
                                        const uint8_t* d_desc2, const int32_t* d_n2, const int32_t* d_cell_start2,

@@ -11,6 +11,8 @@
 // out of two unsigned min/max operations in ascending row order.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include <algorithm>
 #include <climits>
 #include <cstring>
@@ -34,9 +36,16 @@ __global__ __launch_bounds__(256) void k_knn2_fold(const uint2* __restrict__ par
     const int qi = blockIdx.x * 256 + threadIdx.x;
     if (qi >= nq) return;
     int best = INT_MAX, best2 = INT_MAX, idx = -1;
-    for (int c = 0; c < nchunks; c++) {
-        const uint2 p = part[((long long)pair * nchunks + c) * nq + qi];
-        if (p.x == KNN_NONE) continue;
+    // the loads of eight chunks are issued together (they do not depend on the fold), then folded in order
+    for (int c0 = 0; c0 < nchunks; c0 += 8) {
+        uint2 pv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) pv[u] = part[((long long)pair * nchunks + min(c0 + u, nchunks - 1)) * nq + qi];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+        const int c = c0 + u;
+        const uint2 p = pv[u];
+        if (c >= nchunks || p.x == KNN_NONE) continue;
         const int d1 = (int)(p.x >> KNN_IDX_BITS);
         const int d2 = p.y == KNN_NONE ? INT_MAX : (int)(p.y >> KNN_IDX_BITS);
         if (d1 < best) {
@@ -47,6 +56,7 @@ __global__ __launch_bounds__(256) void k_knn2_fold(const uint2* __restrict__ par
             best2 = d1;
         }
         if (d2 < best2) best2 = d2;
+        }
     }
     const long long o = (long long)pair * nq + qi;
     o_idx[o] = idx;
@@ -176,8 +186,8 @@ int orbhip_matcher_create(orbhip_matcher** out, int device) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) m->sm_count = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&m->ev0) != hipSuccess ||
-        hipEventCreate(&m->ev1) != hipSuccess || hipMalloc((void**)&m->d_err, sizeof(int)) != hipSuccess ||
-        hipMemset(m->d_err, 0, sizeof(int)) != hipSuccess) {
+        hipEventCreate(&m->ev1) != hipSuccess || hipMalloc((void**)&m->d_err, 16) != hipSuccess ||
+        hipMemset(m->d_err, 0, 16) != hipSuccess) {
         orbhip_matcher_destroy(m);
         return orb_fail(ORBHIP_EHIP, "stream/event creation failed");
     }
@@ -215,11 +225,17 @@ int orbhip_matcher_synchronize(orbhip_matcher* m) {
         m->last_ms = 0.f;
         (void)hipGetLastError();
     }
-    int flags = 0;
-    HIPCHK(hipMemcpy(&flags, m->d_err, sizeof(int), hipMemcpyDeviceToHost));
-    if (flags) {
-        hipMemset(m->d_err, 0, sizeof(int));
-        return orb_fail(ORBHIP_ECAP, "device output capacity exceeded (flags %d)", flags);
+    struct {
+        int flags, pad;
+        long long need;
+    } st = {0, 0, 0};
+    HIPCHK(hipMemcpy(&st, m->d_err, sizeof(st), hipMemcpyDeviceToHost));
+    if (st.flags) {
+        (void)hipMemset(m->d_err, 0, sizeof(st));
+        if (st.flags & 8)
+            return orb_fail(ORBHIP_ECAP, "the candidate lists of a matcher call need %lld entries, more than the reservation "
+                            "(orbhip_matcher_reserve_candidates); that call produced no matches", st.need);
+        return orb_fail(ORBHIP_ECAP, "device output capacity exceeded (flags %d)", st.flags);
     }
     return ORBHIP_OK;
 }
@@ -252,7 +268,12 @@ static int knn2_check_and_plan(orbhip_matcher* m, const uint8_t* d_q, int nq, pt
     // workgroups deep (every chunk the same number of rows).  A chunk keeps >= 2048 rows, so the unconditional
     // folds of its first rows stay a small share.  Many units: one chunk each.
     const long long units = (long long)qblocks * npairs;
-    const long long resident = (long long)KNN_BLOCKS_PER_CU * m->sm_count;
+    static const int per_cu = [] {
+        const char* e = getenv("ORBHIP_KNN_BLOCKS_PER_CU");  // tuning experiments only
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? v : KNN_BLOCKS_PER_CU;
+    }();
+    const long long resident = (long long)per_cu * m->sm_count;
     int nchunks = (int)std::max<long long>(1, std::min<long long>(resident / units, (nt + 2047) / 2048));
     int chunk_rows = nt > 0 ? (nt + nchunks - 1) / nchunks : 1;
     if (chunk_rows > (int)KNN_IDX_MASK) chunk_rows = KNN_IDX_MASK;

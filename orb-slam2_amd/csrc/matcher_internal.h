@@ -28,7 +28,8 @@ struct orbhip_matcher {
     size_t stage_bytes = 0;
     void* d_work = nullptr;  // workspace of the windowed matchers
     size_t work_bytes = 0;
-    int* d_err = nullptr;  // device error flags, read by orbhip_matcher_synchronize
+    int* d_err = nullptr;  // device error flags (int) + the candidate count a failed reservation needed (int64 at +8), read by orbhip_matcher_synchronize
+    long long cand_reserved = 0;  // > 0: candidate lists of the windowed / projection matchers live in a reservation (asynchronous form)
     int sm_count = 256;
 };
 

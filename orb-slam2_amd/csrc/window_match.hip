@@ -291,6 +291,49 @@ __global__ __launch_bounds__(256) void k_scan_counts(int32_t* __restrict__ count
     }
 }
 
+// Per-frame bases of the candidate lists inside the pair buffer, on the device (the asynchronous form of the
+// matchers: nothing is read back by the host): exclusive scan of the frames' totals.  If the lists need more
+// than `capacity` entries the call cannot run: every list is emptied (starts zeroed, bases -1, so that neither
+// the fill pass nor the sequential stage touches the pair buffer), flag 8 is raised and the count needed is left
+// for orbhip_matcher_synchronize to report.
+__global__ __launch_bounds__(256) void k_frame_bases(const int32_t* __restrict__ totals, int batch, long long capacity,
+                                                     long long* __restrict__ base, int32_t* __restrict__ starts, int nq,
+                                                     int* __restrict__ err) {
+    __shared__ long long carry;
+    __shared__ long long red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < batch; b0 += 256) {
+        const int f = b0 + tid;
+        const long long v = f < batch ? totals[f] : 0;
+        long long incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const long long t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) red[wave] = incl;
+        __syncthreads();
+        long long off = carry;
+        for (int w = 0; w < wave; w++) off += red[w];
+        if (f < batch) base[f] = off + incl - v;
+        __syncthreads();
+        if (tid == 255) carry = off + incl;
+        __syncthreads();
+    }
+    const long long total = carry;
+    if (total > capacity) {
+        for (int f = tid; f < batch; f += 256) base[f] = -1;
+        const long long n = (long long)batch * (nq + 1);
+        for (long long i = tid; i < n; i += 256) starts[i] = 0;
+        if (tid == 0) {
+            atomicOr(err, 8);
+            *(long long*)(err + 2) = total;
+        }
+    }
+}
+
 // Fill pass.  out_idx (explicit queries): indices only, frame f at f*out_cap, overflow flagged.
 // out_pairs (matchers): (distance << 16 | i2) at frame_base[f] + start.
 __global__ __launch_bounds__(256) void k_area_fill(QuerySource s, const KpDev* __restrict__ kp2, const int32_t* __restrict__ cell_start,
@@ -317,6 +360,7 @@ __global__ __launch_bounds__(256) void k_area_fill(QuerySource s, const KpDev* _
             if (pos < out_cap) dst[pos] = i2;
         });
     } else {
+        if (frame_base[f] < 0) return;  // the lists of this call did not fit the reservation
         uint32_t* dst = out_pairs + frame_base[f];
         uint4 d1a = make_uint4(0, 0, 0, 0), d1b = d1a;
         if (q.active) {
@@ -595,6 +639,7 @@ int check_frames(orbhip_matcher* m, int batch, int cap, const OrbFrameBounds& b)
 
 int ensure_work(orbhip_matcher* m, size_t bytes) {
     if (bytes <= m->work_bytes) return ORBHIP_OK;
+    if (hipStreamSynchronize(m->stream) != hipSuccess) return orb_fail(ORBHIP_EHIP, "stream synchronisation failed");
     if (m->d_work) hipFree(m->d_work);
     m->d_work = nullptr;
     m->work_bytes = 0;
@@ -622,13 +667,25 @@ int build_candidates(orbhip_matcher* m, const QuerySource& s, const uint8_t* d_d
     const size_t off_tot = align256(sizeof(int32_t) * (size_t)batch * (nq + 1));
     const size_t off_base = off_tot + align256(sizeof(int32_t) * (size_t)batch);
     const size_t off_pairs = off_base + align256(sizeof(long long) * (size_t)batch);
-    if ((rc = ensure_work(m, off_pairs))) return rc;
+    if ((rc = ensure_work(m, off_pairs + sizeof(uint32_t) * (size_t)m->cand_reserved))) return rc;
     dim3 qgrid((nq * AREA_LPQ + 255) / 256, batch);
     {
         int32_t* starts = (int32_t*)m->d_work;
         int32_t* totals = (int32_t*)((char*)m->d_work + off_tot);
         hipLaunchKernelGGL(k_area_count, qgrid, dim3(256), 0, m->stream, s, d_kp2, d_cell_start2, d_cell_items2, cap2, gg, starts);
         hipLaunchKernelGGL(k_scan_counts, dim3(batch), dim3(256), 0, m->stream, starts, nq, totals);
+    }
+    if (m->cand_reserved > 0) {
+        // asynchronous form: the reservation is the capacity, bases come from a device scan, nothing is read back
+        const long long capacity = m->cand_reserved;  // the workspace holds at least that many past the headers
+        out.starts = (int32_t*)m->d_work;
+        out.d_base = (long long*)((char*)m->d_work + off_base);
+        out.pairs = (uint32_t*)((char*)m->d_work + off_pairs);
+        hipLaunchKernelGGL(k_frame_bases, dim3(1), dim3(256), 0, m->stream, (const int32_t*)((char*)m->d_work + off_tot), batch,
+                           capacity, out.d_base, out.starts, nq, m->d_err);
+        hipLaunchKernelGGL(k_area_fill, qgrid, dim3(256), 0, m->stream, s, d_kp2, d_cell_start2, d_cell_items2, cap2, gg,
+                           out.starts, (int32_t*)nullptr, 0, m->d_err, d_desc1, d_desc2, out.d_base, out.pairs);
+        return ORBHIP_OK;
     }
     std::vector<int32_t> totals(batch);
     HIPCHK(hipMemcpyAsync(totals.data(), (char*)m->d_work + off_tot, sizeof(int32_t) * batch, hipMemcpyDeviceToHost,
@@ -710,7 +767,7 @@ int run_matcher(orbhip_matcher* m, int mode, const OrbKeypoint* d_kp1, const uin
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(m->ev1, m->stream));
-    HIPCHK(hipStreamSynchronize(m->stream));
+    if (m->cand_reserved == 0) HIPCHK(hipStreamSynchronize(m->stream));
     return ORBHIP_OK;
 }
 
@@ -897,6 +954,20 @@ int orbhip_features_in_area_device(orbhip_matcher* m, const OrbKeypoint* d_kp, c
     return ORBHIP_OK;
 }
 
+int orbhip_matcher_reserve_candidates(orbhip_matcher* m, long long entries) {
+    if (!m) return orb_fail(ORBHIP_EINVAL, "null matcher");
+    if (entries < 0 || entries > (1LL << 34)) return orb_fail(ORBHIP_EINVAL, "bad reservation");
+    HIPCHK(hipSetDevice(m->device));
+    if (entries > 0) {
+        // room for the lists plus the per-call headers of the largest batch (starts, totals, bases)
+        const size_t header = align256(sizeof(int32_t) * (size_t)4096 * (ORBHIP_FRAME_MAX_KEYPOINTS + 1));
+        int rc = ensure_work(m, std::min<size_t>(header, (size_t)64 << 20) + sizeof(uint32_t) * (size_t)entries);
+        if (rc) return rc;
+    }
+    m->cand_reserved = entries;
+    return ORBHIP_OK;
+}
+
 int orbhip_search_for_initialization_device(orbhip_matcher* m, const OrbKeypoint* d_kp1, const uint8_t* d_desc1,
                                             const int32_t* d_n1, const OrbKeypoint* d_kp2, const uint8_t* d_desc2,
                                             const int32_t* d_n2, const int32_t* d_cell_start2,
@@ -964,7 +1035,7 @@ int orbhip_search_by_projection_device(orbhip_matcher* m, const OrbProbe* d_prob
 #undef LAUNCH_PROBE
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(m->ev1, m->stream));
-    HIPCHK(hipStreamSynchronize(m->stream));
+    if (m->cand_reserved == 0) HIPCHK(hipStreamSynchronize(m->stream));
     return ORBHIP_OK;
 }
 
@@ -1055,6 +1126,7 @@ int orbhip_search_for_initialization(orbhip_matcher* m, const OrbKeypoint* kp1, 
                                                       ps.cell_items, 1, cap, bounds, ps.prev, window_size, nnratio,
                                                       check_orientation, ps.matches, ps.nmatches)))
         return rc;
+    HIPCHK(hipStreamSynchronize(m->stream));  // the device forms do not wait when a reservation is in place
     if (n1) {
         HIPCHK(hipMemcpy(matches12, ps.matches, sizeof(int32_t) * n1, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(prev_matched, ps.prev, sizeof(float) * 2 * n1, hipMemcpyDeviceToHost));
@@ -1084,6 +1156,7 @@ int orbhip_window_search(orbhip_matcher* m, const OrbKeypoint* kp1, const uint8_
                                           ps.cell_items, 1, cap, bounds, window_size, min_level, max_level, nnratio,
                                           check_orientation, ps.matches, ps.nmatches)))
         return rc;
+    HIPCHK(hipStreamSynchronize(m->stream));  // the device forms do not wait when a reservation is in place
     if (n2) HIPCHK(hipMemcpy(matches21, ps.matches, sizeof(int32_t) * n2, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(nmatches, ps.nmatches, sizeof(int32_t), hipMemcpyDeviceToHost));
     return ORBHIP_OK;
@@ -1143,6 +1216,7 @@ int orbhip_search_by_projection(orbhip_matcher* m, const OrbProbe* probes, const
                                                  taken ? (const uint8_t*)(b + o_t) : nullptr, rule, nnratio, th_dist,
                                                  check_orientation, (int32_t*)(b + o_m), (int32_t*)(b + o_nm))))
         return rc;
+    HIPCHK(hipStreamSynchronize(m->stream));  // the device forms do not wait when a reservation is in place
     if (n2) HIPCHK(hipMemcpy(match_of_feature, b + o_m, sizeof(int32_t) * n2, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(nmatches, b + o_nm, sizeof(int32_t), hipMemcpyDeviceToHost));
     return ORBHIP_OK;

@@ -96,6 +96,13 @@ class ORBextractor:
         (ties to even in the first w & ~3 columns, as an SSE2 build of OpenCV 2.4 rounds them)."""
         _lib.check(self._L.orbhip_extractor_set_gaussian_profile(self._h, int(profile)))
 
+    def torch_stream(self):
+        """The extractor's stream as a torch stream (for device-side ordering against torch's own work)."""
+        import torch
+        if getattr(self, "_tstream", None) is None:
+            self._tstream = torch.cuda.ExternalStream(self._L.orbhip_extractor_stream(self._h), device="cuda:%d" % self.device)
+        return self._tstream
+
     def synchronize(self):
         _lib.check(self._L.orbhip_extractor_synchronize(self._h))
 

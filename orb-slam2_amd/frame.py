@@ -30,10 +30,10 @@ def UndistortKeyPoints(matcher, kp, n, K, dist, out=None):
     cap = kp.numel() * kp.element_size() // 28 // max(batch, 1)
     out = torch.empty_like(kp) if out is None else out
     cam = _lib.OrbCamera(*[float(v) for v in K], *[float(v) for v in dist])
-    torch.cuda.synchronize()
+    matcher._begin()
     _lib.check(_lib.lib().orbhip_undistort_keypoints_device(matcher._h, kp.data_ptr(), n.data_ptr(), batch, cap, cam,
                                                             out.data_ptr()))
-    matcher.synchronize()
+    matcher._end()
     return out
 
 
@@ -62,10 +62,10 @@ class FrameBatch:
         self.cell_start = torch.zeros((self.batch, GRID_CELLS + 1), dtype=torch.int32, device=n.device)
         self.cell_items = torch.zeros((self.batch, self.cap), dtype=torch.int32, device=n.device)
         L = _lib.lib()
-        torch.cuda.synchronize()
+        matcher._begin()
         _lib.check(L.orbhip_frame_grid_device(matcher._h, kp.data_ptr(), n.data_ptr(), self.batch, self.cap, self.bounds,
                                               self.cell_start.data_ptr(), self.cell_items.data_ptr()))
-        matcher.synchronize()
+        matcher._end()
 
     @classmethod
     def from_host(cls, matcher, kps, descs, bounds, cap=None, device="cuda:0"):
@@ -100,10 +100,18 @@ class FrameBatch:
         kp = torch.zeros((b, cap, 7), dtype=torch.float32, device=dev)
         desc = torch.zeros((b, cap, 32), dtype=torch.uint8, device=dev)
         n = torch.zeros(b, dtype=torch.int32, device=dev)
-        torch.cuda.synchronize()
+        # with a matcher in its asynchronous form the whole chain is queued: streams wait for one another on the device
+        queued = getattr(matcher, "_async", False)
+        if queued:
+            extractor.torch_stream().wait_stream(torch.cuda.current_stream(dev))
+        else:
+            torch.cuda.synchronize()
         extractor.extract_batch_device(images.data_ptr(), b, rows, cols, cols, rows * cols, kp.data_ptr(), desc.data_ptr(),
                                        cap, n.data_ptr())
-        extractor.synchronize()
+        if queued:
+            torch.cuda.current_stream(dev).wait_stream(extractor.torch_stream())
+        else:
+            extractor.synchronize()
         if K is None or dist is None or float(dist[0]) == 0.0:
             kp_un, bounds = kp, [0, 0, cols, rows]
         else:
@@ -129,14 +137,14 @@ class FrameBatch:
         self.fv_start = torch.zeros((b, self.node_cap + 1), dtype=torch.int32, device=dev)
         self.fv_feat = torch.zeros((b, cap), dtype=torch.int32, device=dev)
         self.fv_count = torch.zeros(b, dtype=torch.int32, device=dev)
-        torch.cuda.synchronize()
+        self._m._begin()
         # descriptors past a frame's count are transformed too (rows of zeros) and ignored by the FeatureVector
         voc.transform_device(self._m, self.desc.data_ptr(), b * cap, levelsup, self.bow_word.data_ptr(),
                              self.bow_node.data_ptr(), self.bow_weight.data_ptr())
         _lib.check(_lib.lib().orbhip_feature_vector_device(
             self._m._h, self.bow_node.data_ptr(), self.bow_weight.data_ptr(), self.n.data_ptr(), b, cap, self.node_cap,
             self.fv_nodes.data_ptr(), self.fv_start.data_ptr(), self.fv_feat.data_ptr(), self.fv_count.data_ptr()))
-        self._m.synchronize()
+        self._m._end()
 
     def feature_vector(self, f):
         """mFeatVec of frame f on the host: (nodes, start, features)."""

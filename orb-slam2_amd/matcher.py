@@ -26,10 +26,47 @@ class ORBmatcher:
         self._h = C.c_void_p()
         _lib.check(self._L.orbhip_matcher_create(C.byref(self._h), device))
 
+        self.device = device
+        self._async = False
+        self._tstream = None
+
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
             self._L.orbhip_matcher_destroy(self._h)
             self._h = C.c_void_p()
+
+    # ---- stream discipline of the batched device methods ---------------------------------------------
+    # The library works on the matcher's own stream.  Blocking form (default): wait for everything torch has
+    # queued, call, wait for the matcher.  Asynchronous form (after reserve_candidates): the matcher's stream
+    # waits for torch's current stream on the device, the call is queued, torch's current stream then waits for
+    # the matcher's stream on the device; the host never waits until the caller synchronises.
+    def reserve_candidates(self, entries):
+        """orbhip_matcher_reserve_candidates: room for `entries` candidate records (4 bytes each) of the windowed and
+        projection matchers; with a reservation in place they no longer read anything back and do not block.  A
+        call whose candidate lists need more makes the next synchronize() raise with the count needed.  0 returns
+        to the blocking form."""
+        _lib.check(self._L.orbhip_matcher_reserve_candidates(self._h, int(entries)))
+        self._async = entries > 0
+
+    def torch_stream(self):
+        import torch
+        if self._tstream is None:
+            self._tstream = torch.cuda.ExternalStream(self._L.orbhip_matcher_stream(self._h), device="cuda:%d" % self.device)
+        return self._tstream
+
+    def _begin(self):
+        import torch
+        if self._async:
+            self.torch_stream().wait_stream(torch.cuda.current_stream(self.device))
+        else:
+            torch.cuda.synchronize()
+
+    def _end(self):
+        import torch
+        if self._async:
+            torch.cuda.current_stream(self.device).wait_stream(self.torch_stream())
+        else:
+            self.synchronize()
 
     def __del__(self):
         try:
@@ -92,12 +129,13 @@ class ORBmatcher:
         dev = F1.n.device
         m12 = torch.empty((F1.batch, F1.cap), dtype=torch.int32, device=dev)
         nm = torch.empty(F1.batch, dtype=torch.int32, device=dev)
-        torch.cuda.synchronize()
+        self._begin()
         _lib.check(self._L.orbhip_search_for_initialization_device(
             self._h, F1.kp.data_ptr(), F1.desc.data_ptr(), F1.n.data_ptr(), F2.kp.data_ptr(), F2.desc.data_ptr(),
             F2.n.data_ptr(), F2.cell_start.data_ptr(), F2.cell_items.data_ptr(), F1.batch, F1.cap, F2.bounds,
             vbPrevMatched.data_ptr(), int(windowSize), self.mfNNratio, int(self.mbCheckOrientation), m12.data_ptr(),
             nm.data_ptr()))
+        self._end()
         return nm, m12
 
     def WindowSearch(self, F1, F2, windowSize, valid1, minScaleLevel=-1, maxScaleLevel=INT_MAX):
@@ -112,12 +150,13 @@ class ORBmatcher:
         dev = F1.n.device
         m21 = torch.empty((F1.batch, F1.cap), dtype=torch.int32, device=dev)
         nm = torch.empty(F1.batch, dtype=torch.int32, device=dev)
-        torch.cuda.synchronize()
+        self._begin()
         _lib.check(self._L.orbhip_window_search_device(
             self._h, F1.kp.data_ptr(), F1.desc.data_ptr(), F1.n.data_ptr(), valid1.data_ptr(), F2.kp.data_ptr(),
             F2.desc.data_ptr(), F2.n.data_ptr(), F2.cell_start.data_ptr(), F2.cell_items.data_ptr(), F1.batch, F1.cap,
             F2.bounds, int(windowSize), int(minScaleLevel), int(maxScaleLevel), self.mfNNratio,
             int(self.mbCheckOrientation), m21.data_ptr(), nm.data_ptr()))
+        self._end()
         return nm, m21
 
     # acceptance rules of the SearchByProjection overloads (include/orbhip.h)
@@ -141,12 +180,13 @@ class ORBmatcher:
         out = torch.empty((F.batch, F.cap), dtype=torch.int32, device=dev)
         nm = torch.empty(F.batch, dtype=torch.int32, device=dev)
         ori = self.mbCheckOrientation if check_orientation is None else check_orientation
-        torch.cuda.synchronize()
+        self._begin()
         _lib.check(self._L.orbhip_search_by_projection_device(
             self._h, probes.data_ptr(), probe_desc.data_ptr(), nprobes.data_ptr(), int(probes.shape[1]), F.kp.data_ptr(),
             F.desc.data_ptr(), F.n.data_ptr(), F.cell_start.data_ptr(), F.cell_items.data_ptr(), F.batch, F.cap, F.bounds,
             0 if taken is None else taken.data_ptr(), int(rule), self.mfNNratio, int(th_dist), int(ori), out.data_ptr(),
             nm.data_ptr()))
+        self._end()
         return nm, out
 
     def search_by_projection_host(self, probes, probe_desc, kp2, desc2, bounds, rule, taken=None, th_dist=TH_HIGH,
@@ -215,7 +255,7 @@ class ORBmatcher:
         m12 = torch.empty((F1.batch, F1.cap), dtype=torch.int32, device=dev)
         m21 = torch.empty((F1.batch, F1.cap), dtype=torch.int32, device=dev)
         nm = torch.empty(F1.batch, dtype=torch.int32, device=dev)
-        torch.cuda.synchronize()
+        self._begin()
         _lib.check(self._L.orbhip_search_by_bow_device(
             self._h, F1.kp.data_ptr(), F1.desc.data_ptr(), F1.n.data_ptr(), valid1.data_ptr(), F1.fv_nodes.data_ptr(),
             F1.fv_start.data_ptr(), F1.fv_feat.data_ptr(), F1.fv_count.data_ptr(), F2.kp.data_ptr(), F2.desc.data_ptr(),
@@ -223,7 +263,7 @@ class ORBmatcher:
             F2.fv_start.data_ptr(), F2.fv_feat.data_ptr(), F2.fv_count.data_ptr(), F1.batch, F1.cap, F1.node_cap,
             self.mfNNratio, int(self.mbCheckOrientation), int(bool(kf_frame)), m12.data_ptr(), m21.data_ptr(),
             nm.data_ptr()))
-        self.synchronize()
+        self._end()
         return nm, m12, m21
 
     def ComputeDistinctiveDescriptors(self, desc, start):
@@ -235,10 +275,10 @@ class ORBmatcher:
         npts = int(start.numel()) - 1
         idx = torch.empty(max(npts, 1), dtype=torch.int32, device=start.device)
         med = torch.empty(max(npts, 1), dtype=torch.int32, device=start.device)
-        torch.cuda.synchronize()
+        self._begin()
         _lib.check(self._L.orbhip_distinctive_descriptors_device(self._h, desc.data_ptr(), start.data_ptr(), npts,
                                                                  idx.data_ptr(), med.data_ptr()))
-        self.synchronize()
+        self._end()
         return idx[:npts], med[:npts]
 
     def valu_rate(self, mode):

@@ -35,7 +35,7 @@ def main():
     write, nw = per_kernel(sys.argv[2], "WRITE_SIZE")
     out = {"unit": "bytes per launch", "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, "
            "ORBHIP_STREAMS=1, " + (sys.argv[4] if len(sys.argv) > 4 else "python3 bench.py --steps 2 --warmup 1 --no-extra --cpu-sample 0"),
-           "workload": sys.argv[5] if len(sys.argv) > 5 else "256x640x480/1000", "kernels": {}}
+           "workload": sys.argv[5] if len(sys.argv) > 5 else "1024x640x480/1000", "kernels": {}}
     for k in sorted(fetch):
         fr = fetch[k] / nf[k]
         wr = write.get(k, 0.0) / max(nw.get(k, 1), 1)
