@@ -21,8 +21,11 @@ void launch_nms(hipStream_t st, const GeomDev& hg, int batch, int max_cell_h, co
                 const CellDesc* cells, uint32_t* cand, int* n_total, int* err);
 // Fused per-cell FAST (fast_cell.hip); usable when every cell satisfies fast_cell_supported.
 bool fast_cell_supported(int cw, int ch);
+// build_fast_cell_recs fills one record of fast_cell_rec_bytes() bytes per cell (host side, once per image size)
+size_t fast_cell_rec_bytes();
+void build_fast_cell_recs(const GeomDev& hg, const CellDesc* cells, int ncells, void* out);
 void launch_fast_cell(hipStream_t st, const GeomDev& hg, int batch, int max_cw, int max_ch, const uint8_t* pyr,
-                      const GeomDev* dg, const CellDesc* cells, uint32_t* cand, int* n_total, int* err);
+                      const void* recs, uint32_t* cand, int* n_total, int* err);
 void launch_select(hipStream_t st, const GeomDev& hg, int batch, const GeomDev* dg, const CellDesc* cells,
                    uint32_t* cand, const int* n_total, int* n_retain, uint32_t* lvl_list, int* lvl_count, int* err);
 void launch_blur(hipStream_t st, const GeomDev& hg, int batch, int level, const uint8_t* pyr, uint8_t* blur,

@@ -109,6 +109,7 @@ struct orbhip_extractor {
     int last_batch = 0;  // frames of the last chunk (for the stage taps)
 
     DeviceBuf d_geom, d_cells, d_xofs, d_xab, d_ysrc, d_yab, d_disc, d_pattern;
+    DeviceBuf d_fcrecs;  // per-cell records of the fused FAST kernel
     DeviceBuf d_pyr, d_blur, d_score, d_cand, d_cand64, d_ntotal, d_nretain, d_lvl, d_lvlcount, d_angles, d_slots, d_err;
     // staging of the host-pointer entry points: frames in, one output block (counts, keypoints, descriptors)
     // on the device and page-locked mirrors of both, so that a call is two copies and one synchronisation
@@ -325,6 +326,11 @@ int set_size(orbhip_extractor* e, int rows, int cols, int batch) {
         e->cur_rows = e->cur_cols = 0;
         if ((rc = upload(e->d_geom, &g, sizeof(g), e->stream))) return rc;
         if ((rc = upload(e->d_cells, cells.data(), cells.size() * sizeof(CellDesc), e->stream))) return rc;
+        {
+            std::vector<unsigned char> recs(cells.size() * orbk::fast_cell_rec_bytes());
+            orbk::build_fast_cell_recs(g, cells.data(), (int)cells.size(), recs.data());
+            if ((rc = upload(e->d_fcrecs, recs.data(), recs.size(), e->stream))) return rc;
+        }
         if ((rc = upload(e->d_xofs, xofs.data(), xofs.size() * sizeof(int), e->stream))) return rc;
         if ((rc = upload(e->d_xab, xab.data(), xab.size() * sizeof(uint32_t), e->stream))) return rc;
         if ((rc = upload(e->d_ysrc, ysrc.data(), ysrc.size() * sizeof(uint32_t), e->stream))) return rc;
@@ -398,8 +404,7 @@ int run_chunk(orbhip_extractor* e, hipStream_t st, int slot0, const uint8_t* d_i
         for (int l = 0; l < g.nlevels; l++) orbk::launch_score(st, g, batch, l, pyr, score, dg);
     STAGE_MARK(3);
     if (e->fused_fast)
-        orbk::launch_fast_cell(st, g, batch, e->max_cell_w, e->max_cell_h, pyr, dg, e->d_cells.as<CellDesc>(), cand, ntotal,
-                               e->d_err.as<int>());
+        orbk::launch_fast_cell(st, g, batch, e->max_cell_w, e->max_cell_h, pyr, e->d_fcrecs.p, cand, ntotal, e->d_err.as<int>());
     else
         orbk::launch_nms(st, g, batch, e->max_cell_h, score, dg, e->d_cells.as<CellDesc>(), cand, ntotal, e->d_err.as<int>());
     STAGE_MARK(4);
@@ -534,7 +539,7 @@ void orbhip_extractor_destroy(orbhip_extractor* e) {
     if (!e) return;
     hipSetDevice(e->device);
     if (e->stream) hipStreamSynchronize(e->stream);
-    DeviceBuf* bufs[] = {&e->d_geom, &e->d_cells, &e->d_xofs, &e->d_xab, &e->d_ysrc, &e->d_yab, &e->d_disc, &e->d_pattern,
+    DeviceBuf* bufs[] = {&e->d_geom, &e->d_cells, &e->d_fcrecs, &e->d_xofs, &e->d_xab, &e->d_ysrc, &e->d_yab, &e->d_disc, &e->d_pattern,
                          &e->d_pyr, &e->d_blur, &e->d_score, &e->d_cand, &e->d_cand64, &e->d_ntotal, &e->d_nretain, &e->d_lvl,
                          &e->d_lvlcount, &e->d_angles, &e->d_slots, &e->d_err, &e->d_img, &e->d_outblk};
     for (DeviceBuf* b : bufs) b->release();

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "extract_kernels.h"
 #include "fast_measure.h"
@@ -112,53 +113,71 @@ __device__ __forceinline__ uint32_t quick_row_swar(const uint32_t* __restrict__ 
     return (x | (x >> 14)) & 0xfu;
 }
 
+// Everything about a cell that does not depend on the frame, worked out once per image size on the host
+// (build_fast_cell_recs) so that a workgroup starts its tile loads after one scalar load of this record
+// instead of a few hundred scalar and vector instructions of index arithmetic per wave.
+struct FastCellRec {
+    long long src_off;    // byte offset, inside a frame's pyramid, of the tile's first (16-byte aligned) byte
+    long long cand_off;   // offset (keys) of the cell's candidate list inside a frame's arena
+    int cw, ch;           // examined pixels (cw <= 0 or ch <= 0: nothing to do)
+    int stride;           // row stride of the level's padded plane
+    int th, pitch, pc;    // tile rows, tile row pitch in bytes (multiple of 16), pitch / 16
+    int spitch;           // row pitch of the score tile
+    int bw, nwords;       // bitmap words per row, bitmap words
+    uint32_t bw_inv;      // ceil(65536 / bw)
+    int c_lo, g_first;    // first examined tile column, its 4-pixel group
+    int ngroups;          // 4-pixel groups per examined row
+    uint32_t ng_inv;      // floor(2^32 / ngroups) + 1: i / ngroups == mulhi(i, ng_inv) for i < 2^16 (ngroups >= 2)
+    int iters;            // quick-test iterations per wave
+    int dr, dg;           // quotient and remainder of 64 * FC_WAVES / ngroups
+    int step_addr, wrap_addr;
+    uint32_t lowbits, highbits;  // pixels of a row's first / last group outside the examined columns
+    int scb_off, bm_off, qlist_off, clist_off;  // LDS byte offsets
+    int nz;               // dwords to clear per pass (score tile + bitmap)
+    int cand_cap;
+    int per;              // bitmap words per thread in the output phase
+    int pad;
+};
+
 // WPS = waves per SIMD the register allocation aims at: the workgroups a CU holds are limited by their LDS
 // (cell size), and the register budget follows from that number (8 waves per SIMD = 64 VGPRs for the small
 // cells of which four workgroups fit, 6 = 80 VGPRs for the large ones of which three fit).
 template <int WPS>
-__global__ __launch_bounds__(FC_THREADS) __attribute__((amdgpu_waves_per_eu(WPS, WPS))) void k_fast_cell(const uint8_t* __restrict__ pyr, const GeomDev* __restrict__ g,
-                                                          const CellDesc* __restrict__ cells, uint32_t* __restrict__ cand,
-                                                          int* __restrict__ n_total, int* __restrict__ err, int ccap) {
+__global__ __launch_bounds__(FC_THREADS) __attribute__((amdgpu_waves_per_eu(WPS, WPS))) void k_fast_cell(
+    const uint8_t* __restrict__ pyr, const FastCellRec* __restrict__ recs, long long frame_bytes, long long cand_per_frame,
+    int cells_per_frame, int fast_th, uint32_t* __restrict__ cand, int* __restrict__ n_total, int* __restrict__ err, int ccap) {
     extern __shared__ uint4 lds4[];
     __shared__ int cn;
     __shared__ int red[FC_WAVES];
     int c = blockIdx.x, f = blockIdx.y;
     xcd_frame_swizzle(c, f, (int)gridDim.x, (int)gridDim.y);
-    const CellDesc cd = cells[c];
+    const FastCellRec cd = recs[c];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    int* out_total = n_total + (long long)f * g->cells_per_frame + c;
+    int* out_total = n_total + (long long)f * cells_per_frame + c;
     if (cd.cw <= 0 || cd.ch <= 0) {
         if (tid == 0) *out_total = 0;
         return;
     }
     FC_T0
-    const LevelGeom& L = g->lv[cd.level];
-    const int stride = L.stride;
-    const uint8_t* plane = pyr + (long long)f * g->frame_bytes + L.plane_off;
+    const int stride = cd.stride;
     const int cw = cd.cw, ch = cd.ch;
-    const int gx0 = ORB_EDGE + cd.x0 - 3;  // padded-plane column of the tile's first needed byte
-    const int gxs = gx0 & ~15;
-    const int shift = gx0 - gxs;
-    const int th = ch + 6;
-    const int pitch = (shift + cw + 6 + 15) & ~15;
-    const int spitch = (cw + 2 + 3) & ~3;
-    const int bw = (cw + 31) >> 5;  // bitmap words per row
-    const int nwords = bw * ch;
-    const uint32_t bw_inv = (65536u + (uint32_t)bw - 1u) / (uint32_t)bw;
-    const int gy0 = ORB_EDGE + cd.y0 - 3;
+    const int th = cd.th, pitch = cd.pitch;
+    const int spitch = cd.spitch;
+    const int bw = cd.bw, nwords = cd.nwords;
+    const uint32_t bw_inv = cd.bw_inv;
     uint8_t* imgb = (uint8_t*)lds4;
-    uint8_t* scb = imgb + pitch * th;  // (ch + 2) rows of spitch bytes, zero border
-    uint32_t* bm = (uint32_t*)(scb + ((spitch * (ch + 2) + 15) & ~15));
-    uint16_t* qlist = (uint16_t*)(bm + nwords);
-    uint16_t* clist = qlist + FC_QCAP;
+    uint8_t* scb = imgb + cd.scb_off;  // (ch + 2) rows of spitch bytes, zero border
+    uint32_t* bm = (uint32_t*)(imgb + cd.bm_off);
+    uint16_t* qlist = (uint16_t*)(imgb + cd.qlist_off);
+    uint16_t* clist = (uint16_t*)(imgb + cd.clist_off);
 
     {
         // 16 lanes per tile row (pitch <= 256 bytes = 16 chunks), 32 rows per sweep of the block and
         // up to four rows in flight per lane; no index division
-        const int pc = pitch >> 4;
+        const int pc = cd.pc;
         const int cj = tid & 15, r0 = tid >> 4;
         if (cj < pc) {
-            const uint8_t* src = plane + (long long)gy0 * stride + gxs + 16 * cj;
+            const uint8_t* src = pyr + (long long)f * frame_bytes + cd.src_off + 16 * cj;
             uint4* dst = (uint4*)imgb + cj;
             for (int r = r0; r < th; r += 128) {
                 // rows past the end are clamped to the last row (same bytes stored twice), so that
@@ -177,29 +196,26 @@ __global__ __launch_bounds__(FC_THREADS) __attribute__((amdgpu_waves_per_eu(WPS,
     }
 
     FC_T(0)
-    const int tHi = min(max(g->fast_th, 0), 255), tLo = 7;
-    const int c_lo = shift + 3;  // examined tile columns [c_lo, c_lo + cw)
-    const int g_first = c_lo >> 2;
+    const int tHi = min(max(fast_th, 0), 255), tLo = 7;
+    const int c_lo = cd.c_lo;  // examined tile columns [c_lo, c_lo + cw)
+    const int g_first = cd.g_first;
     // A row of the cell is ngroups 4-pixel groups wide; the groups of the cell, row after row, form one sequence
     // that is cut into chunks of 64, one group per lane, so that every lane has work whatever the cell's width.
     // A wave takes chunk (8 it + wave) of the first half of the sequence and the corresponding chunk of the
     // second half in iteration it (two chunks per prefix sum); a lane's (row, group) advances by 512 groups per
     // iteration with the quotient and remainder of 512 / ngroups, which are wave-uniform.
-    const int ngroups = ((c_lo + cw + 3) >> 2) - g_first;
-    const int nchunks = (ngroups * ch + 63) >> 6;
-    const int iters = (nchunks + 2 * FC_WAVES - 1) / (2 * FC_WAVES);
-    const int dr = (64 * FC_WAVES) / ngroups, dg = 64 * FC_WAVES - dr * ngroups;
-    const int step_addr = dr * pitch + 4 * dg, wrap_addr = pitch - 4 * ngroups;
-    // pixels of the first / last group of a row that lie outside the examined columns
-    const uint32_t lowbits = (1u << (c_lo & 3)) - 1u;
-    const uint32_t highbits = 0xfu & ~((1u << (c_lo + cw - 4 * (g_first + ngroups - 1))) - 1u);
-    uint32_t* out = cand + (long long)f * g->cand_per_frame + cd.cand_off;
+    const int ngroups = cd.ngroups;
+    const int iters = cd.iters;
+    const int dr = cd.dr, dg = cd.dg;
+    const int step_addr = cd.step_addr, wrap_addr = cd.wrap_addr;
+    const uint32_t lowbits = cd.lowbits, highbits = cd.highbits;
+    uint32_t* out = cand + (long long)f * cand_per_frame + cd.cand_off;
 
     for (int pass = 0; pass < 2; pass++) {
     const int t = pass == 0 ? tHi : tLo;
     {
         uint32_t* z32 = (uint32_t*)scb;  // score tile and bitmap are contiguous
-        const int nz = (int)((uint32_t*)qlist - z32);
+        const int nz = cd.nz;
         for (int i = tid; i < nz; i += FC_THREADS) z32[i] = 0;
         if (tid == 0) cn = 0;
     }
@@ -217,9 +233,10 @@ __global__ __launch_bounds__(FC_THREADS) __attribute__((amdgpu_waves_per_eu(WPS,
     int rowA, glA, rowB, glB;
     {
         const int iA = (wave << 6) + lane, iB = ((FC_WAVES * iters + wave) << 6) + lane;
-        rowA = iA / ngroups;
+        // 2^32 / 1 does not fit the reciprocal: one group per row means row = index
+        rowA = ngroups == 1 ? iA : (int)__umulhi((uint32_t)iA, cd.ng_inv);
         glA = iA - rowA * ngroups;
-        rowB = iB / ngroups;
+        rowB = ngroups == 1 ? iB : (int)__umulhi((uint32_t)iB, cd.ng_inv);
         glB = iB - rowB * ngroups;
     }
     int adrA = (rowA + 3) * pitch + 4 * (g_first + glA), adrB = (rowB + 3) * pitch + 4 * (g_first + glB);
@@ -314,7 +331,7 @@ __global__ __launch_bounds__(FC_THREADS) __attribute__((amdgpu_waves_per_eu(WPS,
     FC_T(5)
 
     // ---- count, then raster-ordered output --------------------------------------------------------
-    const int per = (nwords + FC_THREADS - 1) / FC_THREADS;
+    const int per = cd.per;
     const int w0 = min(tid * per, nwords), w1 = min(w0 + per, nwords);
     int mine = 0;
     for (int w = w0; w < w1; w++) mine += __popc(bm[w]);
@@ -364,14 +381,27 @@ __global__ __launch_bounds__(FC_THREADS) __attribute__((amdgpu_waves_per_eu(WPS,
     }  // pass
 }
 
-// LDS bytes the kernel needs for cells of up to cw x ch examined pixels (worst-case tile alignment).
-size_t fast_cell_lds_bytes(int cw, int ch, int ccap) {
-    const int pitch = (15 + cw + 6 + 15) & ~15;
-    const int spitch = (cw + 2 + 3) & ~3;
-    const int nwords = ((cw + 31) >> 5) * ch;
-    return (size_t)pitch * (ch + 6) + (size_t)((spitch * (ch + 2) + 15) & ~15) + (size_t)nwords * 4 +
-           (size_t)FC_QCAP * 2 + (size_t)ccap * 2;
+// LDS layout of one cell: tile | score tile | bitmap | per-wave survivor lists | corner list.
+struct FastCellLayout {
+    int pitch, th, spitch, bw, nwords, scb_off, bm_off, qlist_off, clist_off, total;
+};
+static FastCellLayout fast_cell_layout(int shift, int cw, int ch, int ccap) {
+    FastCellLayout l;
+    l.pitch = (shift + cw + 6 + 15) & ~15;
+    l.th = ch + 6;
+    l.spitch = (cw + 2 + 3) & ~3;
+    l.bw = (cw + 31) >> 5;
+    l.nwords = l.bw * ch;
+    l.scb_off = l.pitch * l.th;
+    l.bm_off = l.scb_off + ((l.spitch * (ch + 2) + 15) & ~15);
+    l.qlist_off = l.bm_off + l.nwords * 4;
+    l.clist_off = l.qlist_off + FC_QCAP * 2;
+    l.total = l.clist_off + ccap * 2;
+    return l;
 }
+
+// LDS bytes the kernel needs for cells of up to cw x ch examined pixels (worst-case tile alignment).
+size_t fast_cell_lds_bytes(int cw, int ch, int ccap) { return (size_t)fast_cell_layout(15, cw, ch, ccap).total; }
 
 static int corner_list_cap() {
     static int cap = -1;
@@ -388,16 +418,72 @@ bool fast_cell_supported(int cw, int ch) {
     return 15 + cw + 6 <= 256 && ch <= 249 && fast_cell_lds_bytes(cw, ch, corner_list_cap()) <= 64 * 1024;
 }
 
+size_t fast_cell_rec_bytes() { return sizeof(FastCellRec); }
+
+// One record per cell of the per-frame cell table, in table order.
+void build_fast_cell_recs(const GeomDev& hg, const CellDesc* cells, int ncells, void* out) {
+    FastCellRec* recs = (FastCellRec*)out;
+    const int ccap = corner_list_cap();
+    for (int i = 0; i < ncells; i++) {
+        const CellDesc& cd = cells[i];
+        FastCellRec r;
+        memset(&r, 0, sizeof(r));
+        r.cw = cd.cw;
+        r.ch = cd.ch;
+        if (cd.cw > 0 && cd.ch > 0) {
+            const LevelGeom& L = hg.lv[cd.level];
+            const int gx0 = ORB_EDGE + cd.x0 - 3;  // padded-plane column of the tile's first needed byte
+            const int gxs = gx0 & ~15;
+            const int shift = gx0 - gxs;
+            const int gy0 = ORB_EDGE + cd.y0 - 3;
+            const FastCellLayout l = fast_cell_layout(shift, cd.cw, cd.ch, ccap);
+            r.src_off = L.plane_off + (long long)gy0 * L.stride + gxs;
+            r.cand_off = cd.cand_off;
+            r.stride = L.stride;
+            r.th = l.th;
+            r.pitch = l.pitch;
+            r.pc = l.pitch >> 4;
+            r.spitch = l.spitch;
+            r.bw = l.bw;
+            r.nwords = l.nwords;
+            r.bw_inv = (65536u + (uint32_t)l.bw - 1u) / (uint32_t)l.bw;
+            r.c_lo = shift + 3;
+            r.g_first = r.c_lo >> 2;
+            r.ngroups = ((r.c_lo + cd.cw + 3) >> 2) - r.g_first;
+            r.ng_inv = r.ngroups >= 2 ? (uint32_t)(0x100000000ULL / (uint32_t)r.ngroups) + 1u : 0u;
+            const int nchunks = (r.ngroups * cd.ch + 63) >> 6;
+            r.iters = (nchunks + 2 * FC_WAVES - 1) / (2 * FC_WAVES);
+            r.dr = (64 * FC_WAVES) / r.ngroups;
+            r.dg = 64 * FC_WAVES - r.dr * r.ngroups;
+            r.step_addr = r.dr * l.pitch + 4 * r.dg;
+            r.wrap_addr = l.pitch - 4 * r.ngroups;
+            r.lowbits = (1u << (r.c_lo & 3)) - 1u;
+            r.highbits = 0xfu & ~((1u << (r.c_lo + cd.cw - 4 * (r.g_first + r.ngroups - 1))) - 1u);
+            r.scb_off = l.scb_off;
+            r.bm_off = l.bm_off;
+            r.qlist_off = l.qlist_off;
+            r.clist_off = l.clist_off;
+            r.nz = (l.qlist_off - l.scb_off) / 4;
+            r.cand_cap = cd.cand_cap;
+            r.per = (l.nwords + FC_THREADS - 1) / FC_THREADS;
+        }
+        recs[i] = r;
+    }
+}
+
 void launch_fast_cell(hipStream_t st, const GeomDev& hg, int batch, int max_cw, int max_ch, const uint8_t* pyr,
-                      const GeomDev* dg, const CellDesc* cells, uint32_t* cand, int* n_total, int* err) {
+                      const void* recs, uint32_t* cand, int* n_total, int* err) {
     const int ccap = corner_list_cap();
     const size_t lds = fast_cell_lds_bytes(max_cw, max_ch, ccap);
     dim3 grid(hg.cells_per_frame, batch), block(FC_THREADS);
+    const FastCellRec* r = (const FastCellRec*)recs;
     // four workgroups per CU need <= 40 KB each and 8 waves per SIMD
     if (lds <= 40 * 1024)
-        hipLaunchKernelGGL(k_fast_cell<8>, grid, block, lds, st, pyr, dg, cells, cand, n_total, err, ccap);
+        hipLaunchKernelGGL(k_fast_cell<8>, grid, block, lds, st, pyr, r, hg.frame_bytes, hg.cand_per_frame, hg.cells_per_frame,
+                           hg.fast_th, cand, n_total, err, ccap);
     else
-        hipLaunchKernelGGL(k_fast_cell<6>, grid, block, lds, st, pyr, dg, cells, cand, n_total, err, ccap);
+        hipLaunchKernelGGL(k_fast_cell<6>, grid, block, lds, st, pyr, r, hg.frame_bytes, hg.cand_per_frame, hg.cells_per_frame,
+                           hg.fast_th, cand, n_total, err, ccap);
 }
 
 }  // namespace orbk
