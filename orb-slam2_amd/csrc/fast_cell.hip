@@ -133,10 +133,10 @@ struct FastCellRec {
     int step_addr, wrap_addr;
     uint32_t lowbits, highbits;  // pixels of a row's first / last group outside the examined columns
     int scb_off, bm_off, qlist_off, clist_off;  // LDS byte offsets
-    int nz;               // dwords to clear per pass (score tile + bitmap)
+    int nz;               // 16-byte units to clear per pass (score tile + bitmap)
     int cand_cap;
     int per;              // bitmap words per thread in the output phase
-    int pad;
+    uint32_t cw_inv;      // floor(2^32 / cw) + 1 for cw >= 2
 };
 
 // WPS = waves per SIMD the register allocation aims at: the workgroups a CU holds are limited by their LDS
@@ -214,9 +214,9 @@ __global__ __launch_bounds__(FC_THREADS) __attribute__((amdgpu_waves_per_eu(WPS,
     for (int pass = 0; pass < 2; pass++) {
     const int t = pass == 0 ? tHi : tLo;
     {
-        uint32_t* z32 = (uint32_t*)scb;  // score tile and bitmap are contiguous
+        uint4* z128 = (uint4*)scb;  // score tile and bitmap are contiguous
         const int nz = cd.nz;
-        for (int i = tid; i < nz; i += FC_THREADS) z32[i] = 0;
+        for (int i = tid; i < nz; i += FC_THREADS) z128[i] = make_uint4(0, 0, 0, 0);
         if (tid == 0) cn = 0;
     }
     __syncthreads();
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(FC_THREADS) __attribute__((amdgpu_waves_per_eu(WPS,
     } else {
         // corner list overflowed: visit every examined pixel
         for (int p0 = tid; p0 < cw * ch; p0 += FC_THREADS) {
-            const int r = p0 / cw, x = p0 - r * cw;
+            const int r = cw == 1 ? p0 : (int)__umulhi((uint32_t)p0, cd.cw_inv), x = p0 - r * cw;
             const uint8_t* p = scb + (r + 1) * spitch + x + 1;
             const uint32_t m = p[0];
             if (m != 0 && m > nb_max8(p, spitch)) atomicOr(&bm[r * bw + (x >> 5)], 1u << (x & 31));
@@ -335,12 +335,7 @@ __global__ __launch_bounds__(FC_THREADS) __attribute__((amdgpu_waves_per_eu(WPS,
     const int w0 = min(tid * per, nwords), w1 = min(w0 + per, nwords);
     int mine = 0;
     for (int w = w0; w < w1; w++) mine += __popc(bm[w]);
-    int incl = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int tt = __shfl_up(incl, o);
-        if (lane >= o) incl += tt;
-    }
+    const int incl = (int)wave_inclusive_sum((uint32_t)mine);
     if (lane == 63) red[wave] = incl;
     __syncthreads();
     int off = incl - mine, total = 0;
@@ -394,7 +389,7 @@ static FastCellLayout fast_cell_layout(int shift, int cw, int ch, int ccap) {
     l.nwords = l.bw * ch;
     l.scb_off = l.pitch * l.th;
     l.bm_off = l.scb_off + ((l.spitch * (ch + 2) + 15) & ~15);
-    l.qlist_off = l.bm_off + l.nwords * 4;
+    l.qlist_off = (l.bm_off + l.nwords * 4 + 15) & ~15;  // cleared with 16-byte stores together with the score tile
     l.clist_off = l.qlist_off + FC_QCAP * 2;
     l.total = l.clist_off + ccap * 2;
     return l;
@@ -463,9 +458,10 @@ void build_fast_cell_recs(const GeomDev& hg, const CellDesc* cells, int ncells, 
             r.bm_off = l.bm_off;
             r.qlist_off = l.qlist_off;
             r.clist_off = l.clist_off;
-            r.nz = (l.qlist_off - l.scb_off) / 4;
+            r.nz = (l.qlist_off - l.scb_off) / 16;
             r.cand_cap = cd.cand_cap;
             r.per = (l.nwords + FC_THREADS - 1) / FC_THREADS;
+            r.cw_inv = cd.cw >= 2 ? (uint32_t)(0x100000000ULL / (uint32_t)cd.cw) + 1u : 0u;
         }
         recs[i] = r;
     }
