@@ -211,8 +211,10 @@ __global__ __launch_bounds__(FC_THREADS) __attribute__((amdgpu_waves_per_eu(WPS,
     const uint32_t lowbits = cd.lowbits, highbits = cd.highbits;
     uint32_t* out = cand + (long long)f * cand_per_frame + cd.cand_off;
 
-    for (int pass = 0; pass < 2; pass++) {
-    const int t = pass == 0 ? tHi : tLo;
+    // One FAST call of the reference on the cell image at threshold t.  Written as a body that is expanded twice
+    // (not as a loop over the two thresholds): a loop makes everything the later phases need loop-invariant, the
+    // compiler computes all of it up front and spills dozens of scalar registers to hold it.
+    auto fast_pass = [&](const int t, const bool first) -> bool {
     {
         uint4* z128 = (uint4*)scb;  // score tile and bitmap are contiguous
         const int nz = cd.nz;
@@ -346,9 +348,9 @@ __global__ __launch_bounds__(FC_THREADS) __attribute__((amdgpu_waves_per_eu(WPS,
     }
     FC_T(6)
     // "if(cellKeyPoints[i][j].size()<=3)" -> clear and FAST(cellImage, ..., 7, true)
-    if (pass == 0 && total <= 3) {
+    if (first && total <= 3) {
         __syncthreads();
-        continue;
+        return false;
     }
     if (total > cd.cand_cap) {
         if (tid == 0) atomicOr(err, 1);
@@ -372,8 +374,9 @@ __global__ __launch_bounds__(FC_THREADS) __attribute__((amdgpu_waves_per_eu(WPS,
     }
     if (tid == 0) *out_total = total;
     FC_T(7)
-    break;
-    }  // pass
+    return true;
+    };
+    if (!fast_pass(tHi, true)) fast_pass(tLo, false);
 }
 
 // LDS layout of one cell: tile | score tile | bitmap | per-wave survivor lists | corner list.
