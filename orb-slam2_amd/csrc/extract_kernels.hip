@@ -32,12 +32,16 @@ __device__ __forceinline__ int reflect101(int p, int n) {
 // border are assembled bytewise through the reflection.
 __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ imgs, long long frame_stride,
                                                 long long row_stride, uint8_t* __restrict__ pyr,
-                                                const GeomDev* __restrict__ g, int wide) {
+                                                const GeomDev* __restrict__ g, int wide, uint32_t gpr_inv) {
     const LevelGeom& L = g->lv[0];
-    const int gx = blockIdx.x * 32 + threadIdx.x;  // 16-byte group of the padded row
-    const int y = blockIdx.y * 8 + threadIdx.y;
-    const int f = blockIdx.z;
-    if (gx * 16 >= L.stride || y >= L.ph) return;
+    // the 16-byte groups of the padded plane, row after row, one per thread (a 2-D mapping leaves most lanes of
+    // the last block column idle when the row is not a multiple of 512 bytes)
+    const int gpr = L.stride >> 4;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const int y = (int)__umulhi(i, gpr_inv);  // i / gpr: gpr_inv = floor(2^32 / gpr) + 1, exact for i < 2^32 / gpr
+    const int gx = (int)i - y * gpr;           // 16-byte group of the padded row
+    const int f = blockIdx.y;
+    if (y >= L.ph) return;
     const uint8_t* src = imgs + (long long)f * frame_stride;
     const int sy = reflect101(y - ORB_EDGE, L.h);
     const uint8_t* srow = src + (long long)sy * row_stride;
@@ -1015,8 +1019,10 @@ void launch_level0(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* 
                    long long row_stride, uint8_t* pyr, const GeomDev* dg) {
     const LevelGeom& L = hg.lv[0];
     const int wide = ((uintptr_t)imgs % 16 == 0) && (row_stride % 16 == 0) && (frame_stride % 16 == 0);
-    dim3 grid((L.stride / 16 + 31) / 32, (L.ph + 7) / 8, batch), block(32, 8);
-    hipLaunchKernelGGL(k_level0, grid, block, 0, st, imgs, frame_stride, row_stride, pyr, dg, wide);
+    const int gpr = L.stride / 16;  // >= 2 (a row holds at least the two 16-pixel borders)
+    const uint32_t gpr_inv = (uint32_t)(0x100000000ULL / (uint32_t)gpr) + 1u;
+    dim3 grid(((unsigned)gpr * (unsigned)L.ph + 255u) / 256u, batch), block(256);
+    hipLaunchKernelGGL(k_level0, grid, block, 0, st, imgs, frame_stride, row_stride, pyr, dg, wide, gpr_inv);
 }
 
 void launch_resize(hipStream_t st, const GeomDev& hg, int batch, int level, uint8_t* pyr, const GeomDev* dg,
