@@ -24,7 +24,7 @@ def per_kernel(d, counter):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter or "orbk::" not in r["Kernel_Name"]:
             continue
-        k = r["Kernel_Name"].split("(")[0].replace("orbk::", "")
+        k = r["Kernel_Name"].split("(")[0].replace("orbk::", "").replace("void ", "").split("<")[0].strip()
         tot[k] += float(r["Counter_Value"]) * 1024.0
         n[k] += 1
     return tot, n
