@@ -275,8 +275,11 @@ static int knn2_check_and_plan(orbhip_matcher* m, const uint8_t* d_q, int nq, pt
     }();
     const long long resident = (long long)per_cu * m->sm_count;
     int nchunks = (int)std::max<long long>(1, std::min<long long>(resident / units, (nt + 2047) / 2048));
-    int chunk_rows = nt > 0 ? (nt + nchunks - 1) / nchunks : 1;
-    if (chunk_rows > (int)KNN_IDX_MASK) chunk_rows = KNN_IDX_MASK;
+    // a chunk is a whole number of 8-row groups: its first row is then 256-byte aligned relative to the set (an
+    // odd row count would start every other chunk in the middle of a 64-byte line, and the scan's 64-byte scalar
+    // loads would each straddle two lines: measured 2.30 against 2.13 ms on 4096 x 1.25 M)
+    int chunk_rows = nt > 0 ? (int)((((long long)nt + nchunks - 1) / nchunks + KNN_GROUP - 1) & ~(long long)(KNN_GROUP - 1)) : KNN_GROUP;
+    if (chunk_rows > (int)(KNN_IDX_MASK & ~(unsigned)(KNN_GROUP - 1))) chunk_rows = (int)(KNN_IDX_MASK & ~(unsigned)(KNN_GROUP - 1));
     nchunks = nt > 0 ? (nt + chunk_rows - 1) / chunk_rows : 1;
     if (nchunks > 65535) return orb_fail(ORBHIP_EINVAL, "train set too large");
     plan->qblocks = qblocks;
