@@ -639,9 +639,9 @@ def dist_legs(orb, torch, dist, dev, rank, world, barrier, max_over_ranks):
     torch.cuda.synchronize()
     comm = orb.sharded.Communicator.from_torch_distributed(dist, dev)
     steps = 5
-    dt_c = timed(lambda: orb.sharded.knn2_sharded_rccl(m, comm, dq, nq, shard, e - a, a, out_c), m.synchronize, steps)
+    dt_c = timed(lambda: orb.sharded.knn2_sharded_rccl(m, comm, dq, nq, shard, e - a, a, out_c), m.synchronize, steps, warmup=6)
     dt_t = timed(lambda: orb.sharded.knn2_sharded(m, dq, nq, shard, e - a, a, parts_local, parts_all, out_t, dist=dist),
-                 m.synchronize, steps)
+                 m.synchronize, steps, warmup=3)
     comm.close()
     same = torch.tensor([int(torch.equal(out_c, out_t))], dtype=torch.int32, device=cuda)
     dist.all_reduce(same, op=dist.ReduceOp.MIN)
