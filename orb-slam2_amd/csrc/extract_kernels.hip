@@ -862,6 +862,22 @@ __global__ __launch_bounds__(256) void k_slots(const GeomDev* __restrict__ g, co
 #define DS_ITERS ((DS_ROWS * DS_DWORDS + OD_LPK - 1) / OD_LPK)
 #define OR_ITERS ((31 * 8 + OD_LPK - 1) / OD_LPK)
 
+// Developer instrumentation (-DORBHIP_OD_PHASE_TIMING, never in a shipped build): shader-clock cycles the waves of
+// k_orient_describe spend in each phase, summed; read and reset through orbhip_debug_od_phase.
+#ifdef ORBHIP_OD_PHASE_TIMING
+__device__ unsigned long long od_phase[8];
+#define OD_T0 unsigned long long odt_ = __builtin_readcyclecounter();
+#define OD_T(k)                                                                           \
+    {                                                                                     \
+        const unsigned long long now_ = __builtin_readcyclecounter();                     \
+        if ((threadIdx.x & 63) == 0) atomicAdd(&od_phase[k], now_ - odt_);                \
+        odt_ = now_;                                                                      \
+    }
+#else
+#define OD_T0
+#define OD_T(k)
+#endif
+
 __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
                                                          const GeomDev* __restrict__ g,
                                                          const SlotRec* __restrict__ recs, int key_words,
@@ -874,43 +890,60 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
     // workgroup in LDS instead of a trip through the vector cache per keypoint
     __shared__ uint2 s_otab[31 * 8];
     __shared__ uint4 s_pat[64];
-    if (threadIdx.x < 31 * 8) s_otab[threadIdx.x] = ((const uint2*)otab)[threadIdx.x];
-    if (threadIdx.x < 64) s_pat[threadIdx.x] = ((const uint4*)pattern)[threadIdx.x];
-    __syncthreads();
+    OD_T0
+    // The tables go to LDS through registers, and the barrier that publishes them comes only after the slot record
+    // and both windows have been requested: the three memory round trips of a workgroup (tables, record, windows)
+    // would otherwise run one after the other, and a workgroup lives for little else.
+    uint2 t_otab = make_uint2(0u, 0u);
+    uint4 t_pat = make_uint4(0u, 0u, 0u, 0u);
+    if (threadIdx.x < 31 * 8) t_otab = ((const uint2*)otab)[threadIdx.x];
+    if (threadIdx.x < 64) t_pat = ((const uint4*)pattern)[threadIdx.x];
     int bx = blockIdx.x, f = blockIdx.y;
     xcd_frame_swizzle(bx, f, (int)gridDim.x, (int)gridDim.y);
     const int li = threadIdx.x % OD_LPK;
-    // OD_ROUNDS keypoints per lane group, one after the other: fewer, longer-lived waves
-    for (int round = 0; round < OD_ROUNDS; round++) {
-    const int slot = (bx * OD_ROUNDS + round) * OD_KPB + (threadIdx.x / OD_LPK);
-    if (slot >= g->nfeatures) continue;
-    const SlotRec rec = recs[(long long)f * g->nfeatures + slot];
-    if (!rec.valid) continue;
+    OD_T(0)
+    const int slot = bx * OD_KPB + (threadIdx.x / OD_LPK);
+    SlotRec rec;
+    rec.valid = 0;
+    rec.pix = 0;
+    rec.key = rec.hi = 0;
+    rec.level_oi = 0;
+    rec.scale = rec.kp_size = 0.f;
+    if (slot < g->nfeatures) rec = recs[(long long)f * g->nfeatures + slot];
+    const bool active = rec.valid != 0;
     const uint32_t key = rec.key, hi = rec.hi;
     const int level = rec.level_oi >> 24, oi = rec.level_oi & 0xffffff;
     const int x = key & 0xfff, y = (key >> 12) & 0xfff;
     const int stride = rec.valid - 1;
     const long long pix = rec.pix;
+    OD_T(1)
 
     // all loads of both windows are issued before anything waits on them
     const uint8_t* ocenter = pyr + pix;
     uint32_t disc[OR_ITERS];
-#pragma unroll
-    for (int it = 0; it < OR_ITERS; it++) {
-        const int idx = min(it * OD_LPK + li, 31 * 8 - 1);
-        disc[it] = *(const u32_unaligned*)(ocenter + ((idx >> 3) - ORB_HALF_PATCH) * stride - ORB_HALF_PATCH + 4 * (idx & 7));
-    }
     // window rows start at the dword at or before column x - 18 (planes and strides are 4-byte aligned)
     const int lead = (int)((pix - DS_REACH) & 3);
     const uint8_t* corner = blur + pix - (long long)DS_REACH * stride - DS_REACH - lead;
     uint32_t wreg[DS_ITERS];
+    if (active) {
 #pragma unroll
-    for (int it = 0; it < DS_ITERS; it++) {
-        const int i = min(it * OD_LPK + li, DS_ROWS * DS_DWORDS - 1);
-        const int r = i / DS_DWORDS, cdw = i - r * DS_DWORDS;
-        wreg[it] = *(const uint32_t*)(corner + r * stride + 4 * cdw);
+        for (int it = 0; it < OR_ITERS; it++) {
+            const int idx = min(it * OD_LPK + li, 31 * 8 - 1);
+            disc[it] = *(const u32_unaligned*)(ocenter + ((idx >> 3) - ORB_HALF_PATCH) * stride - ORB_HALF_PATCH + 4 * (idx & 7));
+        }
+#pragma unroll
+        for (int it = 0; it < DS_ITERS; it++) {
+            const int i = min(it * OD_LPK + li, DS_ROWS * DS_DWORDS - 1);
+            const int r = i / DS_DWORDS, cdw = i - r * DS_DWORDS;
+            wreg[it] = *(const uint32_t*)(corner + r * stride + 4 * cdw);
+        }
     }
+    if (threadIdx.x < 31 * 8) s_otab[threadIdx.x] = t_otab;
+    if (threadIdx.x < 64) s_pat[threadIdx.x] = t_pat;
+    __syncthreads();
+    if (!active) return;
 
+    OD_T(2)
     int m10 = 0, m01 = 0;
 #pragma unroll
     for (int it = 0; it < OR_ITERS; it++) {
@@ -932,6 +965,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
     const float angle_deg = fast_atan2_deg((float)m01, (float)m10);
     if (li == 0) angles[(long long)f * g->nfeatures + slot] = angle_deg;
 
+    OD_T(3)
     uint32_t* win = ds_win[threadIdx.x / OD_LPK];
 #pragma unroll
     for (int it = 0; it < DS_ITERS; it++) {
@@ -940,6 +974,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the window is private to this keypoint's lanes
 
+    OD_T(4)
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float angle = angle_deg * factorPI;
     const float a = orbtrig::cos_f<false>(angle), b = orbtrig::sin_f<false>(angle);
@@ -956,8 +991,8 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
         const int v0 = center[r0 * (4 * DS_DWORDS) + c0], v1 = center[r1 * (4 * DS_DWORDS) + c1];
         val |= (uint32_t)(v0 < v1) << j;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // window reads done before the next round overwrites it
-    if (oi >= cap) continue;
+    OD_T(5)
+    if (oi >= cap) return;
     const long long o = (long long)f * cap + oi;
     if (OD_BYTES == 1) desc_out[o * 32 + li] = (uint8_t)val;
     else if (OD_BYTES == 2) ((uint16_t*)(desc_out + o * 32))[li] = (uint16_t)val;
@@ -976,7 +1011,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
         }
         ((uint32_t*)(kp_out + o))[li] = w;
     }
-    }  // round
+    OD_T(6)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1010,6 +1045,14 @@ __global__ void k_test_measure(const uint8_t* patches, int* out, int n) {
 }
 
 }  // namespace orbk
+
+#ifdef ORBHIP_OD_PHASE_TIMING
+extern "C" int orbhip_debug_od_phase(unsigned long long* out8) {
+    unsigned long long z[8] = {0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(orbk::od_phase), sizeof(z)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(orbk::od_phase), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Launchers (host side of this translation unit).
