@@ -28,8 +28,8 @@ void launch_fast_cell(hipStream_t st, const GeomDev& hg, int batch, int max_cw, 
                       const void* recs, uint32_t* cand, int* n_total, int* err);
 void launch_select(hipStream_t st, const GeomDev& hg, int batch, const GeomDev* dg, const CellDesc* cells,
                    uint32_t* cand, const int* n_total, int* n_retain, uint32_t* lvl_list, int* lvl_count, int* err);
-void launch_blur(hipStream_t st, const GeomDev& hg, int batch, int level, const uint8_t* pyr, uint8_t* blur,
-                 const GeomDev* dg, const int taps[7], bool tie_even);
+void launch_blur(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* pyr, uint8_t* blur, const GeomDev* dg,
+                 const int taps[7], bool tie_even);
 // IC_Angle + computeOrbDescriptor + output records, one half-wave per keypoint.
 // lvl_list holds key_words (1 or 2) 32-bit words per keypoint, low word first.
 void launch_orient_describe(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* pyr, const uint8_t* blur,

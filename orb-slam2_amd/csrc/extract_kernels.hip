@@ -696,12 +696,24 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 // neighbour, which is what the fp32 + cvtps2dq column filter of an SSE2 build (SymmColumnVec_32s8u) produces
 // there — every product and partial sum of that filter is exact in fp32 below saturation, so ties are the only
 // difference.
+// All levels of the batch are blurred by ONE launch: the tiles of the levels are numbered one level after the
+// other (BlurPlan), so the small upper levels cost neither a launch of their own nor a tail in which most of the
+// chip waits for their few workgroups.
+struct BlurPlan {
+    int first[ORB_MAX_LEVELS + 1];  // first tile of each level; first[nlevels] = tiles per frame
+    int nx[ORB_MAX_LEVELS];         // tile columns of each level
+    int nlevels;
+};
 template <bool TIE_EVEN>
 __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
-                                              const GeomDev* __restrict__ g, int level, int t0, int t1, int t2, int t3) {
+                                              const GeomDev* __restrict__ g, BlurPlan plan, int t0, int t1, int t2, int t3) {
+    int tile = blockIdx.x, f = blockIdx.y;
+    xcd_frame_swizzle(tile, f, (int)gridDim.x, (int)gridDim.y);
+    int level = 0;
+    while (level + 1 < plan.nlevels && tile >= plan.first[level + 1]) level++;
+    tile -= plan.first[level];
+    const int by = tile / plan.nx[level], bx = tile - by * plan.nx[level];
     const LevelGeom& L = g->lv[level];
-    int bx, by, f;
-    xcd_frame_swizzle3(bx, by, f);
     const int ndw = L.stride >> 2;
     const int dwx = bx * 64 + threadIdx.x;
     // one wave per threadIdx.y: the rows a wave walks are the same for all its lanes (scalar row arithmetic)
@@ -1118,14 +1130,23 @@ void launch_harris_select(hipStream_t st, const GeomDev& hg, int batch, const ui
                        err);
 }
 
-void launch_blur(hipStream_t st, const GeomDev& hg, int batch, int level, const uint8_t* pyr, uint8_t* blur,
-                 const GeomDev* dg, const int taps[7], bool tie_even) {
-    const LevelGeom& L = hg.lv[level];
-    dim3 grid((L.stride / 4 + 63) / 64, (L.ph + 4 * BL_ROWS - 1) / (4 * BL_ROWS), batch), block(64, 4);
+void launch_blur(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* pyr, uint8_t* blur, const GeomDev* dg,
+                 const int taps[7], bool tie_even) {
+    BlurPlan plan;
+    plan.nlevels = hg.nlevels;
+    int total = 0;
+    for (int l = 0; l < hg.nlevels; l++) {
+        const LevelGeom& L = hg.lv[l];
+        plan.first[l] = total;
+        plan.nx[l] = (L.stride / 4 + 63) / 64;
+        total += plan.nx[l] * ((L.ph + 4 * BL_ROWS - 1) / (4 * BL_ROWS));
+    }
+    plan.first[hg.nlevels] = total;
+    dim3 grid(total, batch), block(64, 4);
     if (tie_even)
-        hipLaunchKernelGGL(k_blur<true>, grid, block, 0, st, pyr, blur, dg, level, taps[0], taps[1], taps[2], taps[3]);
+        hipLaunchKernelGGL(k_blur<true>, grid, block, 0, st, pyr, blur, dg, plan, taps[0], taps[1], taps[2], taps[3]);
     else
-        hipLaunchKernelGGL(k_blur<false>, grid, block, 0, st, pyr, blur, dg, level, taps[0], taps[1], taps[2], taps[3]);
+        hipLaunchKernelGGL(k_blur<false>, grid, block, 0, st, pyr, blur, dg, plan, taps[0], taps[1], taps[2], taps[3]);
 }
 
 void launch_orient_describe(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* pyr, const uint8_t* blur,

@@ -416,7 +416,7 @@ int run_chunk(orbhip_extractor* e, hipStream_t st, int slot0, const uint8_t* d_i
         orbk::launch_select(st, g, batch, dg, e->d_cells.as<CellDesc>(), cand, ntotal, nretain, lvl, lvlcount, e->d_err.as<int>());
     STAGE_MARK(5);
     STAGE_MARK(6);  // the orientation is computed by the descriptor kernel
-    for (int l = 0; l < g.nlevels; l++) orbk::launch_blur(st, g, batch, l, pyr, blur, dg, e->gtaps, e->gauss_tie_even);
+    orbk::launch_blur(st, g, batch, pyr, blur, dg, e->gtaps, e->gauss_tie_even);
     STAGE_MARK(7);
     orbk::launch_orient_describe(st, g, batch, pyr, blur, dg, lvl, key_words, lvlcount, e->d_disc.as<uint32_t>(), angles,
                                  e->d_pattern.as<int8_t>(), e->d_slots.as<uint8_t>() + (size_t)slot0 * g.nfeatures * orbk::slot_record_bytes(),
@@ -623,7 +623,7 @@ static int wait_and_collect_times(orbhip_extractor* e) {
     }
     if (e->profiling) {
         const int nl = e->nlevels;
-        const int per_chunk[ORB_NSTAGES] = {1, nl - 1, e->fused_fast ? 0 : nl, 1, e->scoreType == ORBHIP_HARRIS_SCORE ? 4 : 3, 0, nl, 2};
+        const int per_chunk[ORB_NSTAGES] = {1, nl - 1, e->fused_fast ? 0 : nl, 1, e->scoreType == ORBHIP_HARRIS_SCORE ? 4 : 3, 0, 1, 2};
         for (int s = 0; s < ORB_NSTAGES; s++) {
             e->stage_ms[s] = 0.f;
             e->stage_launches[s] = per_chunk[s] * e->prof_chunks;
