@@ -699,6 +699,17 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 // All levels of the batch are blurred by ONE launch: the tiles of the levels are numbered one level after the
 // other (BlurPlan), so the small upper levels cost neither a launch of their own nor a tail in which most of the
 // chip waits for their few workgroups.
+// Raw buffer descriptor over `bytes` bytes at p: loads and stores take a 32-bit lane offset plus a scalar offset,
+// accesses past the end read zero / are dropped.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const void* p, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);
+}
+// a * b + c on the low 24 bits of a and b, as ONE instruction (the compiler prefers multiplies and a 3-operand add)
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "s"(a), "v"(b), "v"(c));
+    return r;
+}
 struct BlurPlan {
     int first[ORB_MAX_LEVELS + 1];  // first tile of each level; first[nlevels] = tiles per frame
     int nx[ORB_MAX_LEVELS];         // tile columns of each level
@@ -740,8 +751,8 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
         if (px0 + j >= ORB_EDGE && px0 + j < L.w + ORB_EDGE) colmask |= 0xffu << (8 * j);
     uint32_t h[7][4];
     uint32_t ctr[7];
-    const uint32_t* col = (const uint32_t*)src;
-    const int sdw = stride >> 2;
+    const uint32_t offl = (uint32_t)xl * 4u, offm = (uint32_t)dwx * 4u, offr = (uint32_t)xr * 4u;
+    const __amdgpu_buffer_rsrc_t rsrc = plane_rsrc(src, stride * ph), rdst = plane_rsrc(dst, stride * ph);
 #pragma unroll
     for (int c0 = 0; c0 < BL_ROWS + 6; c0 += BL_PREFETCH) {
         // issue the loads of BL_PREFETCH rows back to back, then do their arithmetic
@@ -749,11 +760,12 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
 #pragma unroll
         for (int k = 0; k < BL_PREFETCH; k++)
             if (c0 + k < BL_ROWS + 6) {
+                // buffer loads: wave-uniform row offset in a scalar register, 32-bit lane offset, no per-lane
+                // 64-bit address arithmetic
                 const int yy = min(max(y0 - 3 + c0 + k, 0), ph - 1);
-                const uint32_t* row = col + (long long)yy * sdw;
-                ra[k] = row[xl];
-                rb[k] = row[dwx];
-                rc[k] = row[xr];
+                ra[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, offl, yy * stride, 0);
+                rb[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, offm, yy * stride, 0);
+                rc[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, offr, yy * stride, 0);
             }
 #pragma unroll
         for (int k = 0; k < BL_PREFETCH; k++)
@@ -780,10 +792,11 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
                             uint32_t acc[4];
 #pragma unroll
                             for (int j = 0; j < 4; j++) {
-                                uint32_t a = (uint32_t)t3 * h[(i - 3) % 7][j] + 32768u;
-                                a += (uint32_t)t0 * (h[(i - 6) % 7][j] + h[i % 7][j]);
-                                a += (uint32_t)t1 * (h[(i - 5) % 7][j] + h[(i - 1) % 7][j]);
-                                a += (uint32_t)t2 * (h[(i - 4) % 7][j] + h[(i - 2) % 7][j]);
+                                // row sums are below 2^17 and taps below 2^8: 24-bit multiply-adds
+                                uint32_t a = mad_u24((uint32_t)t3, h[(i - 3) % 7][j], 32768u);
+                                a = mad_u24((uint32_t)t0, h[(i - 6) % 7][j] + h[i % 7][j], a);
+                                a = mad_u24((uint32_t)t1, h[(i - 5) % 7][j] + h[(i - 1) % 7][j], a);
+                                a = mad_u24((uint32_t)t2, h[(i - 4) % 7][j] + h[(i - 2) % 7][j], a);
                                 if (TIE_EVEN && px0 + j - ORB_EDGE < (L.w & ~3) && (a & 0xffffu) == 0u) a &= ~0x10000u;
                                 acc[j] = min(a, 0xffffffu);
                             }
@@ -791,7 +804,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
                                                 __builtin_amdgcn_perm(acc[3], acc[2], 0x06020c0cu);
                             o = (bl & colmask) | (o & ~colmask);
                         }
-                        *(uint32_t*)(dst + (long long)y * stride + px0) = o;
+                        __builtin_amdgcn_raw_buffer_store_b32(o, rdst, offm, y * stride, 0);
                     }
                 }
             }
