@@ -560,9 +560,12 @@ template <class KeyT>
 __global__ __launch_bounds__(256) void k_level_select(const GeomDev* __restrict__ g, const CellDesc* __restrict__ cells,
                                                       const KeyT* __restrict__ cand, const int* __restrict__ n_retain,
                                                       KeyT* __restrict__ lvl_list, int* __restrict__ lvl_count,
-                                                      int* __restrict__ err) {
-    __shared__ KeyT buf[SEL_LCAP];
-    __shared__ uint16_t lists[2 * SEL_LCAP];
+                                                      int* __restrict__ err, int lcap) {
+    // staging area for level lists of up to lcap keys (keys, then the two stop lists), sized by the host from the
+    // largest level list this geometry can produce: the workgroups a CU holds follow from it
+    extern __shared__ uint4 lsel_lds[];
+    KeyT* buf = (KeyT*)lsel_lds;
+    uint16_t* lists = (uint16_t*)(buf + lcap);
     __shared__ int aux[ORB_MAX_CELLS_PER_LEVEL + 1];
     __shared__ int red[4];
     const int level = blockIdx.x, f = blockIdx.y;
@@ -604,7 +607,7 @@ __global__ __launch_bounds__(256) void k_level_select(const GeomDev* __restrict_
         if (tid == 0) atomicOr(err, 2);
         total = L.lvl_cap;
     }
-    const bool lstaged = total <= SEL_LCAP;
+    const bool lstaged = total <= lcap;
     KeyT* dst = lstaged ? buf : ll;
     for (int c = wave; c < nCells; c += 4) {
         const int o = aux[c], r = aux[c + 1] - o;
@@ -620,7 +623,7 @@ __global__ __launch_bounds__(256) void k_level_select(const GeomDev* __restrict_
     const int quota = L.quota;
     if (total > quota) {
         if (lstaged) {
-            if (wave == 0) orbsel::wave_nth_element_desc(buf, total, quota, lists, lists + SEL_LCAP, lane);
+            if (wave == 0) orbsel::wave_nth_element_desc(buf, total, quota, lists, lists + lcap, lane);
         } else if (tid == 0) {
             orbsel::nth_element_desc(ll, total, quota);
         }
@@ -1123,12 +1126,21 @@ void launch_nms(hipStream_t st, const GeomDev& hg, int batch, int max_cell_h, co
     hipLaunchKernelGGL(k_nms, grid, block, lds, st, score, dg, cells, cand, n_total, err);
 }
 
+// keys of the largest level list, rounded up to 256 and capped at SEL_LCAP
+static int level_select_cap(const GeomDev& hg) {
+    int cap = 256;
+    for (int l = 0; l < hg.nlevels; l++) cap = std::max(cap, hg.lv[l].lvl_cap);
+    return std::min((cap + 255) & ~255, SEL_LCAP);
+}
+
 void launch_select(hipStream_t st, const GeomDev& hg, int batch, const GeomDev* dg, const CellDesc* cells,
                    uint32_t* cand, const int* n_total, int* n_retain, uint32_t* lvl_list, int* lvl_count, int* err) {
     dim3 per_level(hg.nlevels, batch), per_cell((hg.cells_per_frame + 3) / 4, batch), block(256);
     hipLaunchKernelGGL(k_quota, per_level, block, 0, st, dg, cells, n_total, n_retain);
     hipLaunchKernelGGL(k_cell_select<uint32_t>, per_cell, block, 0, st, dg, cells, cand, n_total, n_retain);
-    hipLaunchKernelGGL(k_level_select<uint32_t>, per_level, block, 0, st, dg, cells, cand, n_retain, lvl_list, lvl_count, err);
+    const int lcap = level_select_cap(hg);
+    hipLaunchKernelGGL(k_level_select<uint32_t>, per_level, block, (size_t)lcap * (4 + 4), st, dg, cells, cand, n_retain,
+                       lvl_list, lvl_count, err, lcap);
 }
 
 void launch_harris_select(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* pyr, const GeomDev* dg,
@@ -1139,8 +1151,9 @@ void launch_harris_select(hipStream_t st, const GeomDev& hg, int batch, const ui
     hipLaunchKernelGGL(k_harris, per_cell, block, 0, st, pyr, dg, cells, cand, n_total, cand64);
     hipLaunchKernelGGL(k_quota, per_level, block, 0, st, dg, cells, n_total, n_retain);
     hipLaunchKernelGGL(k_cell_select<uint64_t>, per_cell4, block, 0, st, dg, cells, cand64, n_total, n_retain);
-    hipLaunchKernelGGL(k_level_select<uint64_t>, per_level, block, 0, st, dg, cells, cand64, n_retain, lvl_list64, lvl_count,
-                       err);
+    const int lcap = level_select_cap(hg);
+    hipLaunchKernelGGL(k_level_select<uint64_t>, per_level, block, (size_t)lcap * (8 + 4), st, dg, cells, cand64, n_retain,
+                       lvl_list64, lvl_count, err, lcap);
 }
 
 void launch_blur(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* pyr, uint8_t* blur, const GeomDev* dg,
