@@ -26,6 +26,7 @@
 namespace {
 
 #include "knn2_kernel.h"
+#include "knn2_mfma.h"
 
 // Chunks are index-contiguous and visited in ascending order, so folding each chunk's two
 // smallest distances with the reference's update rule reproduces the serial scan.
@@ -293,9 +294,19 @@ static int knn2_launch(orbhip_matcher* m, const KnnPlan& plan, const uint8_t* d_
                        const uint8_t* d_t, int nt, ptrdiff_t t_pair_stride, int npairs, int idx_base, uint2* d_part,
                        int32_t* d_idx, int32_t* d_d1, int32_t* d_d2) {
     HIPCHK(hipEventRecord(m->ev0, m->stream));
-    hipLaunchKernelGGL(k_knn2, dim3(plan.qblocks, plan.nchunks, npairs), dim3(256), 0, m->stream, (const uint32_t*)d_q, nq,
-                       (long long)(q_pair_stride / 4), (const uint32_t*)d_t, nt, (long long)(t_pair_stride / 4),
-                       plan.chunk_rows, plan.nchunks, idx_base, d_part, d_idx, d_d1, d_d2);
+    // the matrix-core scan (knn2_mfma.h) unless ORBHIP_KNN_KERNEL=popcount asks for the xor + popcount one
+    static const bool use_mm = [] {
+        const char* e = getenv("ORBHIP_KNN_KERNEL");
+        return !(e && strcmp(e, "popcount") == 0);
+    }();
+    if (use_mm)
+        hipLaunchKernelGGL(k_knn2_mm, dim3(plan.qblocks, plan.nchunks, npairs), dim3(256), 0, m->stream, (const uint32_t*)d_q,
+                           nq, (long long)(q_pair_stride / 4), (const uint32_t*)d_t, nt, (long long)(t_pair_stride / 4),
+                           plan.chunk_rows, plan.nchunks, idx_base, d_part, d_idx, d_d1, d_d2);
+    else
+        hipLaunchKernelGGL(k_knn2, dim3(plan.qblocks, plan.nchunks, npairs), dim3(256), 0, m->stream, (const uint32_t*)d_q, nq,
+                           (long long)(q_pair_stride / 4), (const uint32_t*)d_t, nt, (long long)(t_pair_stride / 4),
+                           plan.chunk_rows, plan.nchunks, idx_base, d_part, d_idx, d_d1, d_d2);
     if (plan.nchunks > 1)
         hipLaunchKernelGGL(k_knn2_fold, dim3(plan.qblocks, npairs), dim3(256), 0, m->stream, (const uint2*)d_part, nq,
                            plan.nchunks, plan.chunk_rows, idx_base, d_idx, d_d1, d_d2);
