@@ -247,6 +247,15 @@ float orbhip_matcher_last_elapsed_ms(orbhip_matcher* m) { return m ? m->last_ms 
 // Launch plan of the scan: query blocks, index-contiguous train chunks (enough workgroups to fill the
 // chip several times over; a chunk never exceeds the key's index field) and the bytes of partial
 // results the chunks exchange (0 with a single chunk).
+// The matrix-core scan (knn2_mfma.h) unless ORBHIP_KNN_KERNEL=popcount asks for the xor + popcount one.
+static bool knn_use_mm() {
+    static const bool v = [] {
+        const char* e = getenv("ORBHIP_KNN_KERNEL");
+        return !(e && strcmp(e, "popcount") == 0);
+    }();
+    return v;
+}
+
 struct KnnPlan {
     int qblocks, nchunks, chunk_rows;
     size_t part_bytes;
@@ -269,18 +278,22 @@ static int knn2_check_and_plan(orbhip_matcher* m, const uint8_t* d_q, int nq, pt
     // workgroups deep (every chunk the same number of rows).  A chunk keeps >= 2048 rows, so the unconditional
     // folds of its first rows stay a small share.  Many units: one chunk each.
     const long long units = (long long)qblocks * npairs;
+    // (the matrix-core kernel holds four workgroups per CU and loses least with exactly one round of them: its
+    // folds grow rarer the longer a chunk is)
     static const int per_cu = [] {
         const char* e = getenv("ORBHIP_KNN_BLOCKS_PER_CU");  // tuning experiments only
         const int v = e ? atoi(e) : 0;
-        return v > 0 ? v : KNN_BLOCKS_PER_CU;
+        return v > 0 ? v : (knn_use_mm() ? 4 : KNN_BLOCKS_PER_CU);
     }();
     const long long resident = (long long)per_cu * m->sm_count;
     int nchunks = (int)std::max<long long>(1, std::min<long long>(resident / units, (nt + 2047) / 2048));
     // a chunk is a whole number of 8-row groups: its first row is then 256-byte aligned relative to the set (an
     // odd row count would start every other chunk in the middle of a 64-byte line, and the scan's 64-byte scalar
     // loads would each straddle two lines: measured 2.30 against 2.13 ms on 4096 x 1.25 M)
-    int chunk_rows = nt > 0 ? (int)((((long long)nt + nchunks - 1) / nchunks + KNN_GROUP - 1) & ~(long long)(KNN_GROUP - 1)) : KNN_GROUP;
-    if (chunk_rows > (int)(KNN_IDX_MASK & ~(unsigned)(KNN_GROUP - 1))) chunk_rows = (int)(KNN_IDX_MASK & ~(unsigned)(KNN_GROUP - 1));
+    // (32 rows: a whole number of the matrix-core kernel's tiles as well)
+    const long long cq = 32;
+    int chunk_rows = nt > 0 ? (int)((((long long)nt + nchunks - 1) / nchunks + cq - 1) & ~(cq - 1)) : (int)cq;
+    if (chunk_rows > (int)(KNN_IDX_MASK & ~(unsigned)(cq - 1))) chunk_rows = (int)(KNN_IDX_MASK & ~(unsigned)(cq - 1));
     nchunks = nt > 0 ? (nt + chunk_rows - 1) / chunk_rows : 1;
     if (nchunks > 65535) return orb_fail(ORBHIP_EINVAL, "train set too large");
     plan->qblocks = qblocks;
@@ -294,12 +307,7 @@ static int knn2_launch(orbhip_matcher* m, const KnnPlan& plan, const uint8_t* d_
                        const uint8_t* d_t, int nt, ptrdiff_t t_pair_stride, int npairs, int idx_base, uint2* d_part,
                        int32_t* d_idx, int32_t* d_d1, int32_t* d_d2) {
     HIPCHK(hipEventRecord(m->ev0, m->stream));
-    // the matrix-core scan (knn2_mfma.h) unless ORBHIP_KNN_KERNEL=popcount asks for the xor + popcount one
-    static const bool use_mm = [] {
-        const char* e = getenv("ORBHIP_KNN_KERNEL");
-        return !(e && strcmp(e, "popcount") == 0);
-    }();
-    if (use_mm)
+    if (knn_use_mm())
         hipLaunchKernelGGL(k_knn2_mm, dim3(plan.qblocks, plan.nchunks, npairs), dim3(256), 0, m->stream, (const uint32_t*)d_q,
                            nq, (long long)(q_pair_stride / 4), (const uint32_t*)d_t, nt, (long long)(t_pair_stride / 4),
                            plan.chunk_rows, plan.nchunks, idx_base, d_part, d_idx, d_d1, d_d2);
