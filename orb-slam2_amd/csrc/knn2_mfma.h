@@ -1,52 +1,55 @@
 // The Hamming k=2 scan on the matrix cores of gfx950.
 //
-// With the bits t_k of a train row as bytes 0 / 1 and the bits q_k of a query as bytes 1 - 2 q_k (+1 / -1), the dot
-// product sum t_k (1 - 2 q_k) = popcount(t) - 2 popcount(t & q) is the Hamming distance minus popcount(q): an exact
-// small integer that orders the rows of one query like the distance does.  v_mfma_i32_32x32x32_i8 forms 32 x 32
-// such products over 32 bits in one instruction, so eight instructions give d - popcount(q) for 32 train rows x 32
-// queries: 4 distances per SIMD cycle at the instruction's issue rate, against the ~1.2 per cycle the xor +
+// With the bits t_k of a train row as operand elements 0 / 1 and the bits q_k of a query as 1 - 2 q_k (+1 / -1), the
+// dot product sum t_k (1 - 2 q_k) = popcount(t) - 2 popcount(t & q) is the Hamming distance minus popcount(q): an
+// exact small integer that orders the rows of one query like the distance does.  The 4-bit float format of
+// v_mfma_f32_32x32x64_f8f6f4 (E2M1: 0x2 = 1.0, 0xA = -1.0, 0 = 0) holds these values exactly and the fp32
+// accumulators hold sums of up to 256 of them exactly, so four instructions give d - popcount(q) for 32 train rows
+// x 32 queries: 8 distances per SIMD cycle at the instruction's issue rate, against the ~1.2 per cycle the xor +
 // popcount instruction stream can issue (knn2_kernel.h), and the result is the same integer.  The order in which
-// the instruction walks its products is irrelevant as long as both operands use the same bit -> (lane, byte)
+// the instruction walks its products is irrelevant as long as both operands use the same bit -> (lane, nibble)
 // rule; the rule here is the one that is cheapest to produce: the lanes of half h = lane / 32 own words 4 h .. 4 h + 3
-// of a row; word i feeds instructions 2 i and 2 i + 1, and byte j of dword k of its eight operand dwords is bit
-// k + 8 j of the word, i.e. (word >> k) & 0x01010101.
+// of a row, word i feeds instruction i, and nibble j of dword k of its four operand dwords is bit k + 4 j of the
+// word: (word >> k) & 0x11111111, moved to bit 1 of the nibble.
 //
 // One workgroup = 256 queries (four waves x two 32-query tiles whose expanded bits stay in registers for the
 // whole scan) against one chunk of train rows, with the arguments, the keys (distance << 22 | chunk-relative
 // row) and the partial results of k_knn2, so the two kernels are interchangeable.  The waves do not cooperate:
 // lane (h, r) of a wave loads 16 bytes of row r of each 32-row tile (the wave reads the tile's 1 KB exactly once)
-// and expands them with 64 full-rate shift / mask instructions, no LDS, no barrier.  The 32 x 32 shape is chosen
-// over 16 x 16 x 64 because of what issues beside it (tools/mfma_valu_probe.hip): six independent vector
-// instructions per matrix instruction cost nothing next to the 32-cycle shape, while the 16-cycle shape hides
-// two and then pays three cycles for every further one.
+// and expands them with 28 full-rate shift / mask instructions, no LDS, no barrier.  (Measured on the way here,
+// tools/mfma_valu_probe.hip and tools/knn_mm_probe.hip: an LDS stage shared by the workgroup lost more at its
+// barriers than the shared expansion saved; 8-bit integer operands need twice the instructions and twice the
+// expansion; next to a 16 x 16 instruction only two independent vector instructions issue for free, next to a
+// 32 x 32 one at least six; and the chip's clock falls to ~1.7 GHz under this load, so rates are quoted per second.)
 //
 // A lane holds the results of 16 of a tile's 32 rows (ascending) for query lane % 32, so it keeps the two
 // smallest keys over half of the rows; the two lanes of a query are merged at the end.  A key can only enter the
-// lane's two smallest if its distance is below the lane's second-best distance: one wave vote per tile on the
-// minima of the lanes' results skips the keyed folds (which are exact whatever the vote lets through).
+// query's two smallest if its distance is below the query's second-best distance so far: one wave vote per tile
+// on the minima of the lanes' results, then one vote per result, skips the keyed folds (which are exact whatever
+// the votes let through).
 #pragma once
 #include <type_traits>
 
 #include "knn2_kernel.h"
 
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x16 __attribute__((ext_vector_type(16)));
-
 #define KMM_THR_NONE 0x400  // above every d - popcount(q)
 #define KMM_BIAS 256        // keys carry d - popcount(q) + 256 until the end
 #define KMM_TILE 32         // train rows per tile
 
-// four operand dwords of one instruction from the lane's word of the row: bits k0 .. k0 + 3 (+ 8 j) of it
-__device__ __forceinline__ i32x4 kmm_bits01(uint32_t w, int k0) {
-    return i32x4{(int)((w >> k0) & 0x01010101u), (int)((w >> (k0 + 1)) & 0x01010101u), (int)((w >> (k0 + 2)) & 0x01010101u),
-                 (int)((w >> (k0 + 3)) & 0x01010101u)};
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// the four operand dwords of one instruction from the lane's word: nibble j of dword k = bit k + 4 j, as 0x2 / 0x0
+__device__ __forceinline__ i32x8 kmm_nibbles(uint32_t w) {
+    return i32x8{(int)((w << 1) & 0x22222222u), (int)(w & 0x22222222u), (int)((w >> 1) & 0x22222222u),
+                 (int)((w >> 2) & 0x22222222u), 0, 0, 0, 0};
 }
 
 __global__ __launch_bounds__(256) void k_knn2_mm(const uint32_t* __restrict__ q, int nq, long long q_pair_words,
-                                                 const uint32_t* __restrict__ t, int nt, long long t_pair_words,
-                                                 int chunk_rows, int nchunks, int idx_base, uint2* __restrict__ part,
-                                                 int32_t* __restrict__ o_idx, int32_t* __restrict__ o_d1,
-                                                 int32_t* __restrict__ o_d2) {
+                                                  const uint32_t* __restrict__ t, int nt, long long t_pair_words,
+                                                  int chunk_rows, int nchunks, int idx_base, uint2* __restrict__ part,
+                                                  int32_t* __restrict__ o_idx, int32_t* __restrict__ o_d1,
+                                                  int32_t* __restrict__ o_d2) {
     const int pair = blockIdx.z, chunk = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, col = lane & 31;
@@ -54,34 +57,30 @@ __global__ __launch_bounds__(256) void k_knn2_mm(const uint32_t* __restrict__ q,
     const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
 #endif
 
-    // ---- the lane's share of the two query tiles, as +1 / -1 bytes: instruction 2 i + u takes bits 4 u .. 4 u + 3
-    // (+ 8 j) of word 4 h + i ----
-    i32x4 bq[2][8];
+    // ---- the lane's share of the two query tiles: +1 (0x2) for a clear bit, -1 (0xA) for a set one ----
+    i32x8 bq[2][4];
 #pragma unroll
     for (int qt = 0; qt < 2; qt++) {
         const int qi = blockIdx.x * 256 + wave * 64 + qt * 32 + col;
         const uint4 w4 = *(const uint4*)(q + (long long)pair * q_pair_words + (long long)min(qi, nq - 1) * 8 + 4 * h);
         const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-        for (int ks = 0; ks < 8; ks++) {
-            const i32x4 b = kmm_bits01(w[ks >> 1], 4 * (ks & 1));
-            int e[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) e[i] = (int)(((uint32_t)b[i] * 0xfeu) | 0x01010101u);  // bit ? -1 : +1
-            bq[qt][ks] = i32x4{e[0], e[1], e[2], e[3]};
+        for (int ks = 0; ks < 4; ks++) {
+            const i32x8 b = kmm_nibbles(w[ks]);
+            bq[qt][ks] = i32x8{(int)(((uint32_t)b[0] << 2) | 0x22222222u), (int)(((uint32_t)b[1] << 2) | 0x22222222u),
+                               (int)(((uint32_t)b[2] << 2) | 0x22222222u), (int)(((uint32_t)b[3] << 2) | 0x22222222u), 0, 0, 0, 0};
         }
     }
 
     const int j0 = chunk * chunk_rows;
     const int rows = min(nt - j0, chunk_rows);
-    // the lane's 16 bytes of row r of the chunk: tp[r * 8 .. + 3] (rows are only 4-byte aligned)
     const uint32_t* __restrict__ tp = t + (long long)pair * t_pair_words + (long long)j0 * 8 + 4 * h;
     uint32_t best[2], best2[2];
-    int thr[2];
+    float thr[2];
 #pragma unroll
     for (int qt = 0; qt < 2; qt++) {
         best[qt] = best2[qt] = KNN_NONE;
-        thr[qt] = KMM_THR_NONE;
+        thr[qt] = (float)KMM_THR_NONE;
     }
 
     struct Row4 {
@@ -96,48 +95,46 @@ __global__ __launch_bounds__(256) void k_knn2_mm(const uint32_t* __restrict__ q,
         v.w[3] = p[3];
         return v;
     };
-    // One tile of 32 rows starting at chunk row r0 whose bits are in `cur`.  TAIL = some of its rows lie past the
-    // chunk (their keys are replaced by "none").
     auto tile = [&](const int r0, const Row4& cur, auto tail_tag) {
         constexpr bool TAIL = decltype(tail_tag)::value;
-        // accumulator input 0 (an inline constant, no registers to preset): acc[qt][reg] = d - popcount(q) for
-        // row r0 + (reg & 3) + 8 (reg >> 2) + 4 h
-        i32x16 acc[2];
+        // acc[qt][reg] = d - popcount(q) for row r0 + (reg & 3) + 8 (reg >> 2) + 4 h
+        f32x16 acc[2];
 #pragma unroll
-        for (int ks = 0; ks < 8; ks++) {
-            const i32x4 a = kmm_bits01(cur.w[ks >> 1], 4 * (ks & 1));
-#pragma unroll
-            for (int qt = 0; qt < 2; qt++) {
-                if (ks == 0)
-                    acc[qt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[qt][0], i32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
-                                                                    0, 0, 0);
-                else
-                    acc[qt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[qt][ks], acc[qt], 0, 0, 0);
-            }
-        }
-        int below[2];
-#pragma unroll
-        for (int qt = 0; qt < 2; qt++) {
-            int m = acc[qt][0];
-#pragma unroll
-            for (int i = 1; i < 16; i++) m = min(m, acc[qt][i]);
-            below[qt] = m - thr[qt];  // negative: some result of the lane is below its second-best
-        }
-        const int rbase = r0 + 4 * h;
-        // key = (acc + 256) << 22 | row: one shift-add per result
-        const uint32_t kbase = ((uint32_t)KMM_BIAS << KNN_IDX_BITS) + (uint32_t)rbase;
-#ifdef KMM_EXP_NOFOLD
-        best[0] ^= (uint32_t)(below[0] | below[1]);  // timing experiment: no vote, no fold
-        if (false) {
+        for (int ks = 0; ks < 4; ks++) {
+#ifdef KMM_EXP_NOEXPAND  // timing experiment: the row's words as they are
+            const i32x8 a = i32x8{(int)cur.w[ks], (int)cur.w[(ks + 1) & 3], (int)cur.w[(ks + 2) & 3], (int)cur.w[(ks + 3) & 3], 0, 0, 0, 0};
 #else
-        if (__builtin_amdgcn_ballot_w64((below[0] | below[1]) < 0) != 0) {
+            const i32x8 a = kmm_nibbles(cur.w[ks]);
 #endif
 #pragma unroll
             for (int qt = 0; qt < 2; qt++) {
-                if (__builtin_amdgcn_ballot_w64(below[qt] < 0) == 0) continue;
-                // which of the sixteen results: all votes first (independent compares into scalar registers), then
-                // a keyed fold for each result some lane needs.  The threshold only falls while the folds run, so
-                // a vote taken before them lets through at least what it must.
+                if (ks == 0)
+                    acc[qt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                        a, bq[qt][0], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 4, 4, 0, 0,
+                        0, 0);
+                else
+                    acc[qt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[qt][ks], acc[qt], 4, 4, 0, 0, 0, 0);
+            }
+        }
+        float below[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; qt++) {
+            float m = acc[qt][0];
+#pragma unroll
+            for (int i = 1; i < 16; i++) m = fminf(m, acc[qt][i]);
+            below[qt] = m - thr[qt];  // negative: some result of the lane is below its second-best
+        }
+        const int rbase = r0 + 4 * h;
+        const uint32_t kbase = ((uint32_t)KMM_BIAS << KNN_IDX_BITS) + (uint32_t)rbase;
+#ifdef KMM_EXP_NOFOLD
+        best[0] ^= (uint32_t)__float_as_int(fminf(below[0], below[1]));  // timing experiment: no vote, no fold
+        if (false) {
+#else
+        if (__builtin_amdgcn_ballot_w64(fminf(below[0], below[1]) < 0.f) != 0) {
+#endif
+#pragma unroll
+            for (int qt = 0; qt < 2; qt++) {
+                if (__builtin_amdgcn_ballot_w64(below[qt] < 0.f) == 0) continue;
                 unsigned long long vote[16];
 #pragma unroll
                 for (int i = 0; i < 16; i++) vote[i] = __builtin_amdgcn_ballot_w64(acc[qt][i] < thr[qt]);
@@ -145,16 +142,19 @@ __global__ __launch_bounds__(256) void k_knn2_mm(const uint32_t* __restrict__ q,
                 for (int i = 0; i < 16; i++) {
                     if (vote[i] == 0) continue;
                     const int ro = (i & 3) + 8 * (i >> 2);
-                    uint32_t key = ((uint32_t)acc[qt][i] << KNN_IDX_BITS) + (kbase + (uint32_t)ro);
+                    uint32_t key = ((uint32_t)(int)acc[qt][i] << KNN_IDX_BITS) + (kbase + (uint32_t)ro);
                     if (TAIL && rbase + ro >= rows) key = KNN_NONE;
                     fold_key(key, best[qt], best2[qt]);
                 }
-                thr[qt] = best2[qt] == KNN_NONE ? KMM_THR_NONE : (int)(best2[qt] >> KNN_IDX_BITS) - KMM_BIAS;
+                // The threshold is the second-smallest key of the QUERY, i.e. over both lanes that share it: the
+                // other lane's keys are of rows before this tile, so a result that ties with it loses on the row.
+                const uint32_t ob = (uint32_t)__shfl_xor((int)best[qt], 32), ob2 = (uint32_t)__shfl_xor((int)best2[qt], 32);
+                const uint32_t u2 = min(max(best[qt], ob), min(best2[qt], ob2));
+                thr[qt] = u2 == KNN_NONE ? (float)KMM_THR_NONE : (float)((int)(u2 >> KNN_IDX_BITS) - KMM_BIAS);
             }
         }
     };
     if (rows > 0) {
-        // the bits of the next tile travel while the current one is multiplied
         const int nfull = rows / KMM_TILE;
         Row4 cur = load_row(col);
         for (int ti = 0; ti < nfull; ti++) {
@@ -179,7 +179,6 @@ __global__ __launch_bounds__(256) void k_knn2_mm(const uint32_t* __restrict__ q,
         fold_key(ob2, best[qt], best2[qt]);
         const int qi = blockIdx.x * 256 + wave * 64 + qt * 32 + col;
         if (h != 0 || qi >= nq) continue;
-        // keys carry d - popcount(q) + 256: back to the distance
         const uint32_t* qp = q + (long long)pair * q_pair_words + (long long)qi * 8;
         int pcq = 0;
 #pragma unroll

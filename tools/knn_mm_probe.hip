@@ -1,6 +1,6 @@
 // Times variants of the matrix-core scan kernel (orb-slam2_amd/csrc/knn2_mfma.h) on one map-shard-shaped problem
-// without the library around it, and the bare issue rate of v_mfma_i32_16x16x64_i8:
-//   -DKMM_EXP_NOFOLD (no vote, no fold).
+// without the library around it (-DKMM_EXP_NOFOLD: no vote, no fold; -DKMM_EXP_CLOCK: the shader clock the chip
+// holds under the kernel), and with -DKMM_RATE the bare issue rate of v_mfma_i32_16x16x64_i8 chains.
 // Results of the variants are not meaningful; only the time is.
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -9,6 +9,7 @@
 namespace {
 #include "../orb-slam2_amd/csrc/knn2_mfma.h"
 }
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 // NACC independent accumulator chains per wave, WAVES_PER_SIMD waves: cycles per instruction on every SIMD
 template <int NACC>
 __global__ __launch_bounds__(256) void k_mfma_rate(int iters, int* out) {
@@ -83,7 +84,7 @@ int main(int argc, char** argv) {
         if (ms < best) best = ms;
     }
     const double clk = prop.clockRate * 1e3;
-    printf("%s nt=%d chunks=%d x %d rows: %.3f ms  %.3e comparisons/s  %.1f SIMD-cycles per instruction of 64 distances\n", VARIANT, nt,
+    printf("%s nt=%d chunks=%d x %d rows: %.3f ms  %.3e comparisons/s  %.1f nominal SIMD-cycles per 64 distances\n", VARIANT, nt,
            nchunks, chunk_rows, best, (double)nq * nt / (best * 1e-3),
            best * 1e-3 * clk * prop.multiProcessorCount * 4 / ((double)nq * nt / 64));
 #ifdef KMM_EXP_CLOCK
