@@ -251,6 +251,16 @@ int orbhip_features_in_area_device(orbhip_matcher* m, const OrbKeypoint* d_kp, c
                                    const OrbAreaQuery* d_queries, int nq, int32_t* d_out_start, int32_t* d_out,
                                    int out_cap);
 
+/* Which kernel scans the train rows of orbhip_knn2_device, orbhip_knn2_device_noalloc, orbhip_knn2 and
+ * orbhip_knn2_sharded.  ORBHIP_SCAN_MATRIX (the default; ORBHIP_KNN_KERNEL=popcount in the environment makes the
+ * other one the default of new handles): descriptor bits as 4-bit matrix operands, the distances of 32 rows x 32
+ * queries from four v_mfma_f32_32x32x64_f8f6f4.  ORBHIP_SCAN_POPCOUNT: xor + popcount per lane, rows through scalar
+ * loads.  Both return the same integers (ties to the lower index); no counterpart in the reference, whose
+ * DescriptorDistance (src/ORBmatcher.cc:1636-1652) is a scalar bit trick. */
+#define ORBHIP_SCAN_MATRIX 0
+#define ORBHIP_SCAN_POPCOUNT 1
+int orbhip_matcher_set_scan_kernel(orbhip_matcher* m, int kind);
+
 /* Asynchronous form of the windowed and projection matchers below (orbhip_search_for_initialization_device,
  * orbhip_window_search_device, orbhip_search_by_projection_device).  Their candidate lists (one 4-byte record per
  * feature that a GetFeaturesInArea call returns) live in a workspace of the handle.  Without a reservation

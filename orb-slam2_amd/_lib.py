@@ -89,6 +89,7 @@ def lib():
     L.orbhip_matcher_stream.argtypes = [vp]
     L.orbhip_matcher_stream.restype = vp
     L.orbhip_matcher_reserve_candidates.argtypes = [vp, C.c_longlong]
+    L.orbhip_matcher_set_scan_kernel.argtypes = [vp, C.c_int]
     L.orbhip_knn2_device.argtypes = [vp, vp, i32, pd, vp, i32, pd, i32, i32, vp, vp, vp]
     L.orbhip_knn2_device_noalloc.argtypes = [vp, vp, i32, pd, vp, i32, pd, i32, i32, vp, vp, vp]
     L.orbhip_knn2_scratch_bytes.argtypes = []

@@ -141,6 +141,8 @@ __global__ __launch_bounds__(256) void k_valu_rate(uint32_t* out, int iters, int
 
 }  // namespace
 
+static int default_scan_kernel();
+
 // Partial results of the chunked scan for the entry point that allocates nothing.  Every GPU the
 // library runs on holds its own copy of this array at its own address until the process ends; host
 // code reaches it only through the address hipGetSymbolAddress returns for the current device
@@ -186,6 +188,7 @@ int orbhip_matcher_create(orbhip_matcher** out, int device) {
     m->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) m->sm_count = prop.multiProcessorCount;
+    m->scan_kernel = default_scan_kernel();
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&m->ev0) != hipSuccess ||
         hipEventCreate(&m->ev1) != hipSuccess || hipMalloc((void**)&m->d_err, 16) != hipSuccess ||
         hipMemset(m->d_err, 0, 16) != hipSuccess) {
@@ -247,13 +250,17 @@ float orbhip_matcher_last_elapsed_ms(orbhip_matcher* m) { return m ? m->last_ms 
 // Launch plan of the scan: query blocks, index-contiguous train chunks (enough workgroups to fill the
 // chip several times over; a chunk never exceeds the key's index field) and the bytes of partial
 // results the chunks exchange (0 with a single chunk).
-// The matrix-core scan (knn2_mfma.h) unless ORBHIP_KNN_KERNEL=popcount asks for the xor + popcount one.
-static bool knn_use_mm() {
-    static const bool v = [] {
-        const char* e = getenv("ORBHIP_KNN_KERNEL");
-        return !(e && strcmp(e, "popcount") == 0);
-    }();
-    return v;
+// Default scan kernel of a new handle: the matrix-core one (knn2_mfma.h) unless ORBHIP_KNN_KERNEL=popcount.
+static int default_scan_kernel() {
+    const char* e = getenv("ORBHIP_KNN_KERNEL");
+    return e && strcmp(e, "popcount") == 0 ? ORBHIP_SCAN_POPCOUNT : ORBHIP_SCAN_MATRIX;
+}
+
+int orbhip_matcher_set_scan_kernel(orbhip_matcher* m, int kind) {
+    if (!m) return orb_fail(ORBHIP_EINVAL, "null matcher");
+    if (kind != ORBHIP_SCAN_MATRIX && kind != ORBHIP_SCAN_POPCOUNT) return orb_fail(ORBHIP_EINVAL, "unknown scan kernel %d", kind);
+    m->scan_kernel = kind;
+    return ORBHIP_OK;
 }
 
 struct KnnPlan {
@@ -280,11 +287,11 @@ static int knn2_check_and_plan(orbhip_matcher* m, const uint8_t* d_q, int nq, pt
     const long long units = (long long)qblocks * npairs;
     // (the matrix-core kernel holds four workgroups per CU and loses least with exactly one round of them: its
     // folds grow rarer the longer a chunk is)
-    static const int per_cu = [] {
+    static const int per_cu_env = [] {
         const char* e = getenv("ORBHIP_KNN_BLOCKS_PER_CU");  // tuning experiments only
-        const int v = e ? atoi(e) : 0;
-        return v > 0 ? v : (knn_use_mm() ? 4 : KNN_BLOCKS_PER_CU);
+        return e ? atoi(e) : 0;
     }();
+    const int per_cu = per_cu_env > 0 ? per_cu_env : (m->scan_kernel == ORBHIP_SCAN_MATRIX ? 4 : KNN_BLOCKS_PER_CU);
     const long long resident = (long long)per_cu * m->sm_count;
     int nchunks = (int)std::max<long long>(1, std::min<long long>(resident / units, (nt + 2047) / 2048));
     // a chunk is a whole number of 8-row groups: its first row is then 256-byte aligned relative to the set (an
@@ -307,7 +314,7 @@ static int knn2_launch(orbhip_matcher* m, const KnnPlan& plan, const uint8_t* d_
                        const uint8_t* d_t, int nt, ptrdiff_t t_pair_stride, int npairs, int idx_base, uint2* d_part,
                        int32_t* d_idx, int32_t* d_d1, int32_t* d_d2) {
     HIPCHK(hipEventRecord(m->ev0, m->stream));
-    if (knn_use_mm())
+    if (m->scan_kernel == ORBHIP_SCAN_MATRIX)
         hipLaunchKernelGGL(k_knn2_mm, dim3(plan.qblocks, plan.nchunks, npairs), dim3(256), 0, m->stream, (const uint32_t*)d_q,
                            nq, (long long)(q_pair_stride / 4), (const uint32_t*)d_t, nt, (long long)(t_pair_stride / 4),
                            plan.chunk_rows, plan.nchunks, idx_base, d_part, d_idx, d_d1, d_d2);

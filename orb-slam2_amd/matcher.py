@@ -48,6 +48,10 @@ class ORBmatcher:
         _lib.check(self._L.orbhip_matcher_reserve_candidates(self._h, int(entries)))
         self._async = entries > 0
 
+    def set_scan_kernel(self, kind):
+        """orbhip_matcher_set_scan_kernel: "matrix" (4-bit matrix-core scan, the default) or "popcount"."""
+        _lib.check(self._L.orbhip_matcher_set_scan_kernel(self._h, {"matrix": 0, "popcount": 1}[kind]))
+
     def torch_stream(self):
         import torch
         if self._tstream is None:

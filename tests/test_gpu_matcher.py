@@ -8,11 +8,21 @@ import pytest
 pytestmark = pytest.mark.gpu
 INT_MAX = 2147483647
 
+# both scan kernels of orbhip_knn2*: the 4-bit matrix-core one (default) and the xor + popcount one
+SCANS = ["matrix", "popcount"]
 
+
+def _matcher(orb, scan, *args):
+    m = orb.ORBmatcher(*args)
+    m.set_scan_kernel(scan)
+    return m
+
+
+@pytest.mark.parametrize("scan", SCANS)
 @pytest.mark.parametrize("nq,nt", [(1, 1), (1, 2), (7, 1), (5, 3), (256, 255), (257, 513), (2000, 2000), (300, 5000)])
-def test_knn2_single_pair(orb, orbref, synth, nq, nt):
+def test_knn2_single_pair(orb, orbref, synth, nq, nt, scan):
     q, t = synth.synth_descriptors(nq, nt, seed=nq * 7919 + nt)
-    m = orb.ORBmatcher(0.6, True)
+    m = _matcher(orb, scan, 0.6, True)
     idx, d1, d2 = m.knn2(q, t)
     ridx, rd1, rd2 = orbref.knn2(q, t)
     assert np.array_equal(idx, ridx)
@@ -20,10 +30,12 @@ def test_knn2_single_pair(orb, orbref, synth, nq, nt):
     assert np.array_equal(d2, rd2)
 
 
-@pytest.mark.parametrize("nt", [8, 9, 15, 16, 511, 512, 513, 519, 520, 527, 1031, 4099])
-def test_knn2_group_boundaries(orb, orbref, synth, nt):
-    """Train sizes around the scan's internal boundaries: groups of 8 rows, the 512 rows folded unconditionally
-    before the threshold filter starts, and the rows left over after the last whole group."""
+@pytest.mark.parametrize("scan", SCANS)
+@pytest.mark.parametrize("nt", [8, 9, 15, 16, 31, 32, 33, 63, 64, 65, 511, 512, 513, 519, 520, 527, 1031, 4099])
+def test_knn2_group_boundaries(orb, orbref, synth, nt, scan):
+    """Train sizes around the scans' internal boundaries: groups of 8 rows, the 512 rows folded unconditionally
+    before the threshold filter starts and the rows left over after the last whole group (popcount kernel); tiles
+    of 32 rows and the partial last tile (matrix kernel)."""
     q, t = synth.synth_descriptors(300, nt, seed=4242 + nt)
     # the best rows of some queries sit at the very end and right after the unconditional part
     q[0] = t[nt - 1]
@@ -33,13 +45,14 @@ def test_knn2_group_boundaries(orb, orbref, synth, nt):
         t[513] = t[512]
         q[3] = t[nt - 2]
         t[nt - 1] = t[nt - 2]
-    m = orb.ORBmatcher(0.6, True)
+    m = _matcher(orb, scan, 0.6, True)
     idx, d1, d2 = m.knn2(q, t)
     ridx, rd1, rd2 = orbref.knn2(q, t)
     assert np.array_equal(idx, ridx) and np.array_equal(d1, rd1) and np.array_equal(d2, rd2)
 
 
-def test_knn2_late_improvements(orb, orbref):
+@pytest.mark.parametrize("scan", SCANS)
+def test_knn2_late_improvements(orb, orbref, scan):
     """Distances that keep falling along the scan (row j differs from the query in about 200 - j/20 bits), so the
     filtered steady state takes its exact-fold path again and again, with equal distances in neighbouring rows."""
     rng = np.random.default_rng(77)
@@ -51,47 +64,89 @@ def test_knn2_late_improvements(orb, orbref):
         k = max(0, 200 - j // 20)
         bits[j, rng.permutation(256)[:k]] = 1
     t = base ^ np.packbits(bits, axis=1)
-    m = orb.ORBmatcher(0.6, True)
+    m = _matcher(orb, scan, 0.6, True)
     idx, d1, d2 = m.knn2(q, t)
     ridx, rd1, rd2 = orbref.knn2(q, t)
     assert np.array_equal(idx, ridx) and np.array_equal(d1, rd1) and np.array_equal(d2, rd2)
 
 
-def test_knn2_empty_train(orb):
-    m = orb.ORBmatcher()
+@pytest.mark.parametrize("scan", SCANS)
+def test_knn2_empty_train(orb, scan):
+    m = _matcher(orb, scan)
     q = np.zeros((5, 32), np.uint8)
     idx, d1, d2 = m.knn2(q, np.zeros((0, 32), np.uint8))
     assert (idx == -1).all() and (d1 == INT_MAX).all() and (d2 == INT_MAX).all()
 
 
-def test_knn2_ties_take_first_index(orb, orbref):
+@pytest.mark.parametrize("scan", SCANS)
+def test_knn2_ties_take_first_index(orb, orbref, scan):
     """All train rows identical: best = row 0, second = the same distance (multiplicity)."""
     q = np.random.default_rng(0).integers(0, 256, (70, 32), dtype=np.uint8)
     t = np.tile(np.arange(32, dtype=np.uint8), (900, 1))
-    m = orb.ORBmatcher()
+    m = _matcher(orb, scan)
     idx, d1, d2 = m.knn2(q, t)
     assert (idx == 0).all() and np.array_equal(d1, d2)
     ridx, rd1, rd2 = orbref.knn2(q, t)
     assert np.array_equal(idx, ridx) and np.array_equal(d1, rd1) and np.array_equal(d2, rd2)
 
 
-def test_knn2_batched_pairs(orb, orbref, synth):
+@pytest.mark.parametrize("scan", SCANS)
+def test_knn2_extreme_popcounts(orb, orbref, scan):
+    """Descriptors of all zeros / all ones and their neighbours: distances 0, 1, 255 and 256, query popcounts 0 and
+    256 (the matrix kernel carries distance - popcount(query) through its accumulators), equal distances on both
+    sides of a tile boundary."""
+    rng = np.random.default_rng(5)
+    nt = 200
+    t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    t[3] = 0
+    t[40] = 0xff
+    t[41] = 0xff
+    t[41, 7] = 0x7f
+    t[31] = t[32] = t[17]
+    t[63] = t[64] = t[100] ^ np.uint8(0x10)
+    q = rng.integers(0, 256, (100, 32), dtype=np.uint8)
+    q[0] = 0
+    q[1] = 0xff
+    q[2] = 0
+    q[2, 0] = 1
+    q[3] = t[17]
+    q[4] = t[100]
+    q[5] = ~t[3]
+    m = _matcher(orb, scan)
+    idx, d1, d2 = m.knn2(q, t)
+    ridx, rd1, rd2 = orbref.knn2(q, t)
+    assert np.array_equal(idx, ridx) and np.array_equal(d1, rd1) and np.array_equal(d2, rd2)
+    assert d1[0] == 0 and idx[0] == 3 and d1[1] == 0 and idx[1] == 40 and d2[1] == 1 and idx[3] == 17 and d2[3] == 0
+    # only all-zero / all-one rows: every distance is 0 or 256
+    t2 = np.zeros((70, 32), np.uint8)
+    t2[1::2] = 0xff
+    idx, d1, d2 = m.knn2(q[:2], t2)
+    ridx, rd1, rd2 = orbref.knn2(q[:2], t2)
+    assert np.array_equal(idx, ridx) and np.array_equal(d1, rd1) and np.array_equal(d2, rd2)
+    assert list(idx) == [0, 1] and list(d1) == [0, 0] and list(d2) == [0, 0]
+    idx, d1, d2 = m.knn2(q[:2], t2[:2])
+    assert list(d2) == [256, 256]
+
+
+@pytest.mark.parametrize("scan", SCANS)
+def test_knn2_batched_pairs(orb, orbref, synth, scan):
     P, nq, nt = 9, 300, 400
     qs, ts = zip(*[synth.synth_descriptors(nq, nt, seed=100 + p) for p in range(P)])
     q, t = np.stack(qs), np.stack(ts)
-    m = orb.ORBmatcher()
+    m = _matcher(orb, scan)
     idx, d1, d2 = m.knn2(q, t)
     for p in range(P):
         ridx, rd1, rd2 = orbref.knn2(q[p], t[p])
         assert np.array_equal(idx[p], ridx) and np.array_equal(d1[p], rd1) and np.array_equal(d2[p], rd2)
 
 
-def test_knn2_chunked_large_train(orb, orbref, synth):
+@pytest.mark.parametrize("scan", SCANS)
+def test_knn2_chunked_large_train(orb, orbref, synth, scan):
     """Few queries against many rows: the train set is split over workgroups and folded."""
     q, t = synth.synth_descriptors(64, 200000, seed=3)
     t[150000:150050] = t[10]  # duplicates far apart: the first index must win
     q[0] = t[10]
-    m = orb.ORBmatcher()
+    m = _matcher(orb, scan)
     idx, d1, d2 = m.knn2(q, t)
     ridx, rd1, rd2 = orbref.knn2(q, t)
     assert np.array_equal(idx, ridx) and np.array_equal(d1, rd1) and np.array_equal(d2, rd2)
