@@ -12,6 +12,6 @@ python3 tools/pmc_sq_summary.py profiles/${name}_pmc_sq.json \
   "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES, ORBHIP_STREAMS=1, python3 bench.py --steps 1 --warmup 1 --no-extra --cpu-sample 0 (1024 x 640x480 frames, 1000 features, per launch)" \
   gpurun_out/${tag}_sq > /dev/null
 python3 tools/pmc_sq_summary.py profiles/${name}_matcher_pmc_sq.json \
-  "rocprofv3 --pmc (same SQ counters), python3 tools/prof_matchers.py: k_knn2 on 4096 pairs of 2000 x 2000 and on 4000 x 1.25 M, windowed / projection matchers on 256 pairs of 2000 keypoints, BoW legs" \
+  "rocprofv3 --pmc (same SQ counters), python3 tools/prof_matchers.py: k_knn2_mm on 4096 pairs of 2000 x 2000 and on 4000 x 1.25 M, windowed / projection matchers on 256 pairs of 2000 keypoints, BoW legs" \
   gpurun_out/${tag}_msq > /dev/null
 ls -la profiles/${name}_*
