@@ -56,6 +56,13 @@ __global__ __launch_bounds__(256) void k_level0(const uint8_t* __restrict__ imgs
             out.z = *(const u32_unaligned*)(srow + x0 + 8);
             out.w = *(const u32_unaligned*)(srow + x0 + 12);
         }
+    } else if ((x0 == -ORB_EDGE && L.w > ORB_EDGE) || (x0 == L.w && L.w > ORB_EDGE)) {
+        // a group that lies wholly in the left / right border mirrors 16 consecutive source pixels: columns
+        // 16 .. 1 for the left border, w - 2 .. w - 17 for the right one -> one 16-byte run, bytes reversed
+        const uint8_t* run = srow + (x0 < 0 ? 1 : L.w - 1 - ORB_EDGE);
+        const uint32_t a = *(const u32_unaligned*)(run), b = *(const u32_unaligned*)(run + 4),
+                       c = *(const u32_unaligned*)(run + 8), d = *(const u32_unaligned*)(run + 12);
+        out = make_uint4(__builtin_bswap32(d), __builtin_bswap32(c), __builtin_bswap32(b), __builtin_bswap32(a));
     } else {
         uint32_t wds[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
