@@ -153,6 +153,27 @@ def test_knn2_chunked_large_train(orb, orbref, synth, scan):
     assert idx[0] == 10 and d1[0] == 0 and d2[0] == 0
 
 
+@pytest.mark.parametrize("scan", SCANS)
+def test_knn2_train_rows_at_4_byte_alignment(orb, orbref, synth, scan):
+    """The train set only has to be 4-byte aligned (the matrix kernel reads it in 16-byte pieces all the same)."""
+    import torch
+    nq, nt = 300, 1500
+    q, t = synth.synth_descriptors(nq, nt, seed=23)
+    ridx, rd1, rd2 = orbref.knn2(q, t)
+    m = _matcher(orb, scan)
+    dq = torch.from_numpy(q).cuda()
+    for off in (4, 8, 12, 20):
+        buf = torch.zeros(nt * 32 + 64, dtype=torch.uint8, device="cuda")
+        buf[off:off + nt * 32] = torch.from_numpy(t.reshape(-1)).cuda()
+        out = torch.zeros((3, nq), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        m.knn2_device(dq.data_ptr(), nq, nq * 32, buf.data_ptr() + off, nt, nt * 32, 1, 0, out[0].data_ptr(),
+                      out[1].data_ptr(), out[2].data_ptr())
+        m.synchronize()
+        o = out.cpu().numpy()
+        assert np.array_equal(o[0], ridx) and np.array_equal(o[1], rd1) and np.array_equal(o[2], rd2), off
+
+
 def test_sharded_merge_and_ratio(orb, orbref, synth):
     """Index-contiguous shards merged on the device equal the unsharded scan; ratio test forms."""
     import torch
