@@ -1,51 +1,153 @@
 #!/usr/bin/env python3
-"""Randomised parity sweep of the extractor against the oracle (GPU box): image sizes, feature counts,
-level counts, scale factors, thresholds and both score types.  Prints the failing configurations."""
+"""Randomised parity sweep on the GPU box: the HIP extractor and the Hamming scan against the CPU oracle on
+configurations drawn from a seeded generator, for a time budget.  Everything is compared bit for bit (keypoint
+fields including the orientation's float bits, descriptors, kNN indices and distances).  Writes one JSON summary.
+   python3 tools/parity_sweep.py [--seconds 240] [--seed 1] [--out gpurun_out/parity_sweep.json]
+A geometry whose cells reach past the border must be refused by both sides (the reference would read outside
+the image there); anything else the device refuses is counted separately."""
+import argparse
 import importlib
+import json
 import os
 import sys
+import time
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
-import orbref  # noqa: E402
 
-orb = importlib.import_module("orb-slam2_amd")
-rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
-n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-max_w = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
-max_h = int(sys.argv[4]) if len(sys.argv) > 4 else 800
-bad = 0
-for case in range(n_cases):
-    w, h = int(rng.integers(96, max_w)), int(rng.integers(96, max_h))
-    nf = int(rng.integers(50, 3000 * max(1, max_w // 1000)))
-    nl = int(rng.integers(1, 9))
-    sf = float(rng.choice([1.1, 1.2, 1.2, 1.3, 1.5, 2.0]))
-    th = int(rng.integers(5, 45))
-    st = int(rng.integers(0, 2))
-    seed = int(rng.integers(0, 10000))
-    img = orb.synth.synth_image(w, h, seed)
-    flat = rng.random() < 0.2
-    if flat:
-        img = (img // 8 * 8).astype(np.uint8)  # flatter image: threshold-7 fallback and sparse cells
-    tag = "%d %d %d %d %.1f %d %d %d%s" % (w, h, nf, nl, sf, th, st, seed, " flat" if flat else "")
-    try:
-        dev = orb.ORBextractor(nf, sf, nl, st, th, device=0, max_width=w, max_height=h)
-    except orb.OrbhipError as e:
-        print("SKIP  %s: %s" % (tag, e))
-        continue
-    ref = orbref.RefExtractor(nf, sf, nl, st, th)
-    try:
-        rkp, rdesc = ref(img)
-        dkp, ddesc = dev(img)
-    except Exception as e:  # geometry the reference cannot run either
-        print("ERR   %s: %s" % (tag, e))
-        continue
-    ok = len(rkp) == len(dkp) and np.array_equal(rkp.view(np.uint32), dkp.view(np.uint32)) and np.array_equal(rdesc, ddesc)
-    print("%s %s n=%d" % ("ok   " if ok else "FAIL ", tag, len(rkp)), flush=True)
-    bad += 0 if ok else 1
-    dev.close()
-print("%d failing of %d" % (bad, n_cases))
-sys.exit(1 if bad else 0)
+
+def image_of(kind, rng, synth, w, h, idx):
+    if kind == "scene":
+        return synth.synth_image(w, h, idx)
+    if kind == "scene_flat":
+        return (synth.synth_image(w, h, idx) // 8 * 8).astype(np.uint8)
+    if kind == "noise":
+        return rng.integers(0, 256, (h, w), dtype=np.uint8)
+    if kind == "smooth":
+        yy, xx = np.mgrid[0:h, 0:w]
+        a, b = rng.uniform(0.02, 0.2, 2)
+        return np.clip(127 + 100 * np.sin(a * xx + rng.uniform(0, 6)) * np.cos(b * yy) + rng.integers(-3, 4, (h, w)), 0, 255).astype(np.uint8)
+    if kind == "blocks":
+        s = int(rng.integers(2, 9))
+        small = rng.integers(0, 256, ((h + s - 1) // s, (w + s - 1) // s), dtype=np.uint8)
+        return np.kron(small, np.ones((s, s), np.uint8))[:h, :w].copy()
+    raise ValueError(kind)
+
+
+def same_extraction(rkp, rdesc, dkp, ddesc):
+    if len(rkp) != len(dkp):
+        return "count %d vs %d" % (len(rkp), len(dkp))
+    for f in ("x", "y", "size", "response", "octave", "class_id"):
+        if not np.array_equal(rkp[f], dkp[f]):
+            return f
+    if not np.array_equal(rkp["angle"].view(np.uint32), dkp["angle"].view(np.uint32)):
+        return "angle bits"
+    if not np.array_equal(rdesc, ddesc):
+        return "%d descriptor bits" % int(np.unpackbits(rdesc ^ ddesc).sum())
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=240.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "parity_sweep.json"))
+    args = ap.parse_args()
+    import orbref
+    orb = importlib.import_module("orb-slam2_amd")
+    rng = np.random.default_rng(args.seed)
+    t_end = time.time() + args.seconds
+    ex = {"configurations": 0, "frames": 0, "keypoints": 0, "refused_geometries": 0, "unsupported_by_device": 0, "mismatching_frames": 0,
+          "failures": []}
+    kn = {"calls": 0, "comparisons": 0, "mismatching_calls": 0, "failures": []}
+    kinds = ["scene", "scene", "scene_flat", "noise", "smooth", "blocks"]
+    last_print = time.time()
+    while time.time() < t_end:
+        # ---- one extractor configuration, a few frames through it (single and batched) -------------
+        w, h = int(rng.integers(96, 1400)), int(rng.integers(96, 800))
+        nf = int(rng.integers(50, 4001))
+        nl = int(rng.integers(1, 9))
+        sf = float(rng.choice([1.1, 1.2, 1.2, 1.3, 1.5, 2.0]))
+        th = int(rng.integers(5, 45))
+        st = int(rng.integers(0, 2))
+        gauss = int(rng.integers(0, 2))
+        cfg = dict(w=w, h=h, nfeatures=nf, nlevels=nl, scale=sf, fast_th=th, score=st, gauss_profile=gauss)
+        imgs = [image_of(str(rng.choice(kinds)), rng, orb.synth, w, h, int(rng.integers(0, 100000))) for _ in range(3)]
+        dev, dev_err, ref_err, outs, refs = None, None, None, None, None
+        try:
+            dev = orb.ORBextractor(nf, sf, nl, st, th, device=0, max_width=w, max_height=h, max_batch=3)
+            dev.set_gaussian_profile(gauss)
+            outs = [dev(imgs[0])] + list(dev.extract_batch(np.stack(imgs))[1:])
+        except orb.OrbhipError as e:
+            dev_err = e
+        finally:
+            if dev is not None:
+                dev.close()
+        orbref.lib().orbref_set_gauss_profile(gauss)
+        try:
+            ref = orbref.RefExtractor(nf, sf, nl, st, th)
+            refs = [ref(im) for im in imgs]
+        except RuntimeError as e:
+            ref_err = e
+        finally:
+            orbref.lib().orbref_set_gauss_profile(0)
+        if dev_err is not None or ref_err is not None:
+            # a geometry whose cells reach past the border (the reference would read outside the image there) must
+            # be refused by both; other device refusals (sizes it does not support) are only counted
+            geom = dev_err is not None and dev_err.code == -5
+            if (ref_err is not None) != geom:
+                ex["mismatching_frames"] += 1
+                ex["failures"].append(dict(cfg, what="refusal: device %r, oracle %r" % (dev_err, ref_err)))
+            ex["refused_geometries" if geom else "unsupported_by_device"] += 1
+            continue
+        ex["configurations"] += 1
+        for (rkp, rdesc), (dkp, ddesc) in zip(refs, outs):
+            ex["frames"] += 1
+            ex["keypoints"] += len(rkp)
+            bad = same_extraction(rkp, rdesc, dkp, ddesc)
+            if bad:
+                ex["mismatching_frames"] += 1
+                ex["failures"].append(dict(cfg, what=bad))
+        # ---- a few Hamming scans of random shape through both kernels -------------------------------
+        for scan in ("matrix", "popcount"):
+            nq, nt = int(rng.integers(1, 700)), int(rng.choice([rng.integers(1, 100), rng.integers(100, 6000), rng.integers(6000, 60000)]))
+            pairs = int(rng.integers(1, 4)) if nt < 6000 else 1
+            q = rng.integers(0, 256, (pairs, nq, 32), dtype=np.uint8)
+            t = rng.integers(0, 256, (pairs, nt, 32), dtype=np.uint8)
+            if rng.random() < 0.5:  # near-duplicates: small distances and ties
+                k = int(rng.integers(1, min(nq, nt) + 1))
+                t[:, rng.integers(0, nt, k)] = q[:, rng.integers(0, nq, k)]
+                if nt > 3:
+                    t[:, nt - 1] = t[:, 0]
+            m = orb.ORBmatcher(0.6, True)
+            m.set_scan_kernel(scan)
+            idx, d1, d2 = m.knn2(q, t)
+            ok = True
+            for p in range(pairs):
+                ridx, rd1, rd2 = orbref.knn2(q[p], t[p])
+                ok = ok and np.array_equal(idx[p], ridx) and np.array_equal(d1[p], rd1) and np.array_equal(d2[p], rd2)
+            kn["calls"] += 1
+            kn["comparisons"] += pairs * nq * nt
+            if not ok:
+                kn["mismatching_calls"] += 1
+                kn["failures"].append(dict(scan=scan, nq=nq, nt=nt, pairs=pairs))
+            m.close()
+        if time.time() - last_print > 30:
+            last_print = time.time()
+            print("extraction: %d configurations, %d frames, %d mismatching; scans: %d calls, %d mismatching" %
+                  (ex["configurations"], ex["frames"], ex["mismatching_frames"], kn["calls"], kn["mismatching_calls"]), flush=True)
+    res = {"what": "tools/parity_sweep.py --seconds %g --seed %d: HIP path against the CPU oracle, bit for bit" % (args.seconds, args.seed),
+           "extraction": ex, "hamming_knn2": kn}
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    with open(args.out, "w") as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps({"extraction": {k: v for k, v in ex.items() if k != "failures"}, "failures": ex["failures"][:5],
+                      "hamming_knn2": {k: v for k, v in kn.items() if k != "failures"}, "knn_failures": kn["failures"][:5]}))
+    return 1 if ex["mismatching_frames"] or kn["mismatching_calls"] else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
