@@ -953,24 +953,29 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
     const long long pix = rec.pix;
     OD_T(1)
 
-    // all loads of both windows are issued before anything waits on them
-    const uint8_t* ocenter = pyr + pix;
+    // all loads of both windows are issued before anything waits on them.  Buffer loads over the frame's two
+    // arenas (the frame is the same for the whole workgroup): 32-bit offsets, no per-lane 64-bit address arithmetic
+    const long long fbase = (long long)f * g->frame_bytes;
+    const __amdgpu_buffer_rsrc_t rs_pyr = plane_rsrc(pyr + fbase, (int)g->frame_bytes),
+                                 rs_blur = plane_rsrc(blur + fbase, (int)g->frame_bytes);
+    const uint32_t pixf = (uint32_t)(pix - fbase);
     uint32_t disc[OR_ITERS];
     // window rows start at the dword at or before column x - 18 (planes and strides are 4-byte aligned)
-    const int lead = (int)((pix - DS_REACH) & 3);
-    const uint8_t* corner = blur + pix - (long long)DS_REACH * stride - DS_REACH - lead;
+    const int lead = (int)((pixf - DS_REACH) & 3u);
+    const uint32_t ocorner = pixf - (uint32_t)(ORB_HALF_PATCH * stride + ORB_HALF_PATCH);
+    const uint32_t corner = pixf - (uint32_t)(DS_REACH * stride + DS_REACH + lead);
     uint32_t wreg[DS_ITERS];
     if (active) {
 #pragma unroll
         for (int it = 0; it < OR_ITERS; it++) {
             const int idx = min(it * OD_LPK + li, 31 * 8 - 1);
-            disc[it] = *(const u32_unaligned*)(ocenter + ((idx >> 3) - ORB_HALF_PATCH) * stride - ORB_HALF_PATCH + 4 * (idx & 7));
+            disc[it] = __builtin_amdgcn_raw_buffer_load_b32(rs_pyr, ocorner + __umul24((uint32_t)(idx >> 3), (uint32_t)stride) + (uint32_t)(4 * (idx & 7)), 0, 0);
         }
 #pragma unroll
         for (int it = 0; it < DS_ITERS; it++) {
             const int i = min(it * OD_LPK + li, DS_ROWS * DS_DWORDS - 1);
             const int r = i / DS_DWORDS, cdw = i - r * DS_DWORDS;
-            wreg[it] = *(const uint32_t*)(corner + r * stride + 4 * cdw);
+            wreg[it] = __builtin_amdgcn_raw_buffer_load_b32(rs_blur, corner + __umul24((uint32_t)r, (uint32_t)stride) + (uint32_t)(4 * cdw), 0, 0);
         }
     }
     if (threadIdx.x < 31 * 8) s_otab[threadIdx.x] = t_otab;
