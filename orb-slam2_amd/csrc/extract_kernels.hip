@@ -24,6 +24,17 @@ __device__ __forceinline__ int reflect101(int p, int n) {
     return p;
 }
 
+// Raw buffer descriptor over `bytes` bytes at p: loads and stores take a 32-bit lane offset plus a scalar offset,
+// accesses past the end read zero / are dropped.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const void* p, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);
+}
+// a * b + c on the low 24 bits of a and b, as ONE instruction (the compiler prefers multiplies and a 3-operand add)
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "s"(a), "v"(b), "v"(c));
+    return r;
+}
 // ---------------------------------------------------------------------------------------------
 // Level 0: copyMakeBorder(image, temp, 16.., BORDER_REFLECT_101) (src/ORBextractor.cc:814).
 // One thread writes 16 aligned bytes of the padded plane.  The border is 16 px wide, so an interior
@@ -105,10 +116,11 @@ __device__ __forceinline__ void reflect_range(int a, int b, int n, int& lo, int&
 __device__ __forceinline__ void resize_rows(const uint8_t* __restrict__ rows, int rpitch, int row0, const int sx[4],
                                             const int sx1[4], const int a0[4], const int a1[4],
                                             const uint32_t* __restrict__ ytab_s, const uint32_t* __restrict__ ytab_b,
-                                            int ybase, int yend, int h, uint8_t* __restrict__ dst, int dstride,
-                                            uint32_t keep) {
+                                            int ybase, int yend, int h, __amdgpu_buffer_rsrc_t dst, uint32_t dst_off,
+                                            int dstride, uint32_t keep) {
     int cached_row = -1;
     uint32_t ct[4] = {0, 0, 0, 0};
+#pragma unroll 2
     for (int y = ybase; y < yend; y++) {
         const int dy = reflect101(y - ORB_EDGE, h);
         const uint32_t ys = ytab_s[dy], yb = ytab_b[dy];
@@ -134,7 +146,7 @@ __device__ __forceinline__ void resize_rows(const uint8_t* __restrict__ rows, in
             ct[b] = t1[b];
         }
         cached_row = sy1;
-        *(uint32_t*)(dst + (long long)y * dstride) = out & keep;
+        __builtin_amdgcn_raw_buffer_store_b32(out & keep, dst, dst_off, y * dstride, 0);  // row offset rides in a scalar register
     }
 }
 
@@ -201,7 +213,8 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, const
     const int yend = min(ybase + RZ_ROWS, L.ph);
     __syncthreads();
     if (!col_ok || ybase >= yend) return;
-    uint8_t* dst = frame + L.plane_off + dwx * 4;
+    const __amdgpu_buffer_rsrc_t dst = plane_rsrc(frame + L.plane_off, L.stride * L.ph);
+    const uint32_t dst_off = (uint32_t)dwx * 4u;
     const uint32_t* ytab_s = ysrc + L.rz_y_off;
     const uint32_t* ytab_b = yab + L.rz_y_off;
     // offsets are formed as non-negative ints and added to the tile / plane origin: no pointer ever
@@ -213,9 +226,9 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, const
             sx1[b] -= X0;
         }
         resize_rows((const uint8_t*)rz_lds, lds_pitch, sy_min, sx, sx1, a0, a1, ytab_s, ytab_b, ybase, yend, L.h, dst,
-                    L.stride, keep);
+                    dst_off, L.stride, keep);
     } else {
-        resize_rows(src, P.stride, 0, sx, sx1, a0, a1, ytab_s, ytab_b, ybase, yend, L.h, dst, L.stride, keep);
+        resize_rows(src, P.stride, 0, sx, sx1, a0, a1, ytab_s, ytab_b, ybase, yend, L.h, dst, dst_off, L.stride, keep);
     }
 }
 
@@ -709,17 +722,6 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 // All levels of the batch are blurred by ONE launch: the tiles of the levels are numbered one level after the
 // other (BlurPlan), so the small upper levels cost neither a launch of their own nor a tail in which most of the
 // chip waits for their few workgroups.
-// Raw buffer descriptor over `bytes` bytes at p: loads and stores take a 32-bit lane offset plus a scalar offset,
-// accesses past the end read zero / are dropped.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const void* p, int bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);
-}
-// a * b + c on the low 24 bits of a and b, as ONE instruction (the compiler prefers multiplies and a 3-operand add)
-__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) {
-    uint32_t r;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "s"(a), "v"(b), "v"(c));
-    return r;
-}
 struct BlurPlan {
     int first[ORB_MAX_LEVELS + 1];  // first tile of each level; first[nlevels] = tiles per frame
     int nx[ORB_MAX_LEVELS];         // tile columns of each level
