@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on the GPU box: the HIP extractor and the Hamming scan against the CPU oracle on
-configurations drawn from a seeded generator, for a time budget.  Everything is compared bit for bit (keypoint
+configurations drawn from a seeded generator, and the two windowed matchers on random frame pairs, for a time budget.  Everything is compared bit for bit (keypoint
 fields including the orientation's float bits, descriptors, kNN indices and distances).  Writes one JSON summary.
    python3 tools/parity_sweep.py [--seconds 240] [--seed 1] [--out gpurun_out/parity_sweep.json]
 A geometry whose cells reach past the border must be refused by both sides (the reference would read outside
@@ -63,6 +63,10 @@ def main():
     ex = {"configurations": 0, "frames": 0, "keypoints": 0, "refused_geometries": 0, "unsupported_by_device": 0, "mismatching_frames": 0,
           "failures": []}
     kn = {"calls": 0, "comparisons": 0, "mismatching_calls": 0, "failures": []}
+    wm = {"pairs": 0, "mismatching_calls": 0, "failures": []}  # SearchForInitialization + WindowSearch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_window as wt  # frame generators and the compare-with-the-oracle helpers of the tests
+    INT_MAX = 2147483647
     kinds = ["scene", "scene", "scene_flat", "noise", "smooth", "blocks"]
     last_print = time.time()
     while time.time() < t_end:
@@ -135,18 +139,41 @@ def main():
                 kn["mismatching_calls"] += 1
                 kn["failures"].append(dict(scan=scan, nq=nq, nt=nt, pairs=pairs))
             m.close()
+        # ---- the two windowed matchers on a few random frame pairs ------------------------------------------
+        try:
+            ww, wh = int(rng.integers(200, 1400)), int(rng.integers(160, 800))
+            levels = int(rng.integers(1, 6))
+            ties, cluster, ori = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+            sizes = [int(rng.integers(0, 60)), int(rng.integers(60, 900)), int(rng.integers(900, 2600))]
+            fr, frng = wt.frames_for(orbref, int(rng.integers(0, 1 << 30)), sizes, ww, wh, levels=levels, ties=ties, cluster=cluster)
+            pairs, valids = [], []
+            for kp, de in fr:
+                pairs.append((kp, de) + wt.moved(orbref, frng, kp, de, ww, wh, noise_bits=int(rng.integers(0, 8)),
+                                                 shift=float(rng.uniform(1, 12)), rot=float(rng.uniform(0, 360))))
+                valids.append((frng.random(len(kp)) < 0.7).astype(np.uint8))
+            window = int(rng.choice([10, 30, 50, 100, 200]))
+            ratio = float(rng.choice([0.6, 0.75, 0.9]))
+            bounds = [0, 0, ww, wh]
+            wm["pairs"] += 2 * len(pairs)
+            wt._run_search_init(orb, orbref, None, pairs, bounds, window, ratio, ori, cap=wt._pad_equal(pairs))
+            lo = int(rng.integers(-1, levels))
+            wt._run_window(orb, orbref, pairs, valids, bounds, window, lo, INT_MAX if rng.random() < 0.7 else lo + 1, ratio, ori)
+        except AssertionError as e:
+            wm["mismatching_calls"] += 1
+            wm["failures"].append(dict(w=ww, h=wh, levels=levels, ties=ties, cluster=cluster, ori=ori, sizes=sizes, what=str(e)[:200]))
         if time.time() - last_print > 30:
             last_print = time.time()
             print("extraction: %d configurations, %d frames, %d mismatching; scans: %d calls, %d mismatching" %
                   (ex["configurations"], ex["frames"], ex["mismatching_frames"], kn["calls"], kn["mismatching_calls"]), flush=True)
     res = {"what": "tools/parity_sweep.py --seconds %g --seed %d: HIP path against the CPU oracle, bit for bit" % (args.seconds, args.seed),
-           "extraction": ex, "hamming_knn2": kn}
+           "extraction": ex, "hamming_knn2": kn, "windowed_matchers": wm}
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, "w") as f:
         json.dump(res, f, indent=1)
     print(json.dumps({"extraction": {k: v for k, v in ex.items() if k != "failures"}, "failures": ex["failures"][:5],
-                      "hamming_knn2": {k: v for k, v in kn.items() if k != "failures"}, "knn_failures": kn["failures"][:5]}))
-    return 1 if ex["mismatching_frames"] or kn["mismatching_calls"] else 0
+                      "hamming_knn2": {k: v for k, v in kn.items() if k != "failures"}, "knn_failures": kn["failures"][:5],
+                      "windowed_matchers": {k: v for k, v in wm.items() if k != "failures"}, "window_failures": wm["failures"][:5]}))
+    return 1 if ex["mismatching_frames"] or kn["mismatching_calls"] or wm["mismatching_calls"] else 0
 
 
 if __name__ == "__main__":
