@@ -29,11 +29,16 @@ inline int ceil_int(double v) { int i = (int)v; return i + (i < v); }
 // inverse of the order-preserving float -> unsigned map of the HARRIS_SCORE keys: IEEE bits of the response
 inline uint32_t ordered_bits_to_float_bits(uint32_t u) { return (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; }
 
+// Bumped whenever a buffer of any handle is (re)allocated or released: a captured launch sequence holds raw
+// addresses and is only replayed while this is what it was at capture time.
+static unsigned long long g_buffer_generation = 0;
+
 struct DeviceBuf {
     void* p = nullptr;
     size_t bytes = 0;
     int ensure(size_t need) {
         if (need <= bytes) return ORBHIP_OK;
+        g_buffer_generation++;
         if (p) hipFree(p);
         p = nullptr;
         bytes = 0;
@@ -42,6 +47,7 @@ struct DeviceBuf {
         return ORBHIP_OK;
     }
     void release() {
+        g_buffer_generation++;
         if (p) hipFree(p);
         p = nullptr;
         bytes = 0;
@@ -55,6 +61,7 @@ struct PinnedBuf {
     size_t bytes = 0;
     int ensure(size_t need) {
         if (need <= bytes) return ORBHIP_OK;
+        g_buffer_generation++;
         if (p) hipHostFree(p);
         p = nullptr;
         bytes = 0;
@@ -115,6 +122,19 @@ struct orbhip_extractor {
     // on the device and page-locked mirrors of both, so that a call is two copies and one synchronisation
     DeviceBuf d_img, d_outblk;
     PinnedBuf h_img, h_outblk;
+
+    // One frame per call (how src/Frame.cc:61 uses the class): the whole sequence of a call — image copy in, ~20
+    // kernels, result block out — captured once per image size as a graph and replayed with one launch.
+    hipGraphExec_t graph_exec = nullptr;
+    struct GraphKey {
+        int rows = 0, cols = 0, cap = 0;
+        bool tie_even = false;
+        unsigned long long generation = 0;
+        bool operator==(const GraphKey& o) const {
+            return rows == o.rows && cols == o.cols && cap == o.cap && tie_even == o.tie_even && generation == o.generation;
+        }
+    } graph_key;
+    bool graph_off = false;  // capture failed once, or ORBHIP_GRAPH=0: plain launches from then on
 };
 
 namespace {
@@ -476,6 +496,10 @@ int orbhip_extractor_create(orbhip_extractor** out, int nfeatures, float scale_f
             break;
         }
         {
+            const char* gr = getenv("ORBHIP_GRAPH");  // 0: never capture the one-frame sequence as a graph
+            e->graph_off = gr && gr[0] == '0';
+        }
+        {
             const char* env = getenv("ORBHIP_STREAMS");
             int nw = env ? atoi(env) : 2;
             nw = std::max(1, std::min(nw, 16));
@@ -542,6 +566,7 @@ void orbhip_extractor_destroy(orbhip_extractor* e) {
     DeviceBuf* bufs[] = {&e->d_geom, &e->d_cells, &e->d_fcrecs, &e->d_xofs, &e->d_xab, &e->d_ysrc, &e->d_yab, &e->d_disc, &e->d_pattern,
                          &e->d_pyr, &e->d_blur, &e->d_score, &e->d_cand, &e->d_cand64, &e->d_ntotal, &e->d_nretain, &e->d_lvl,
                          &e->d_lvlcount, &e->d_angles, &e->d_slots, &e->d_err, &e->d_img, &e->d_outblk};
+    if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
     for (DeviceBuf* b : bufs) b->release();
     e->h_img.release();
     e->h_outblk.release();
@@ -700,14 +725,52 @@ int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int batch, in
                 for (int r = 0; r < rows; r++) memcpy(hin + (size_t)f * img_bytes + (size_t)r * cols, src + (ptrdiff_t)r * row_stride, cols);
             }
         }
-        HIPCHK(hipMemcpyAsync(e->d_img.p, hin, img_bytes * b, hipMemcpyHostToDevice, e->stream));
-        rc = orbhip_extract_batch_device(e, e->d_img.as<uint8_t>(), b, rows, cols, cols, (ptrdiff_t)img_bytes,
-                                         (OrbKeypoint*)(dblk + kp_off), dblk + desc_off, cap, (int*)(dblk + n_off));
-        if (rc) return rc;
-        // error flags and the whole output block come back with ONE synchronisation; the counts say how much of it is valid
-        HIPCHK(hipMemcpyAsync(dblk, e->d_err.p, sizeof(int), hipMemcpyDeviceToDevice, e->stream));
         const size_t used = desc_off + (size_t)32 * cap * b;
-        HIPCHK(hipMemcpyAsync((void*)hblk, dblk, used, hipMemcpyDeviceToHost, e->stream));
+        // the queue of one chunk: image in, kernel sequence, error flags and the whole output block back (ONE
+        // synchronisation; the counts say how much of the block is valid)
+        auto enqueue = [&]() -> int {
+            HIPCHK(hipMemcpyAsync(e->d_img.p, hin, img_bytes * b, hipMemcpyHostToDevice, e->stream));
+            const int r2 = orbhip_extract_batch_device(e, e->d_img.as<uint8_t>(), b, rows, cols, cols, (ptrdiff_t)img_bytes,
+                                                       (OrbKeypoint*)(dblk + kp_off), dblk + desc_off, cap, (int*)(dblk + n_off));
+            if (r2) return r2;
+            HIPCHK(hipMemcpyAsync(dblk, e->d_err.p, sizeof(int), hipMemcpyDeviceToDevice, e->stream));
+            HIPCHK(hipMemcpyAsync((void*)hblk, dblk, used, hipMemcpyDeviceToHost, e->stream));
+            return ORBHIP_OK;
+        };
+        bool replayed = false;
+        if (batch == 1 && !e->profiling && !e->graph_off) {
+            // buffers first (nothing may be allocated while the stream is being captured)
+            if ((rc = set_size(e, rows, cols, 1))) return rc;
+            orbhip_extractor::GraphKey key;
+            key.rows = rows; key.cols = cols; key.cap = cap; key.tie_even = e->gauss_tie_even; key.generation = g_buffer_generation;
+            if (!e->graph_exec || !(key == e->graph_key)) {
+                if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
+                e->graph_exec = nullptr;
+                HIPCHK(hipStreamSynchronize(e->stream));  // geometry uploads of set_size are not part of the graph
+                hipGraph_t graph = nullptr;
+                bool ok = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                if (ok) {
+                    const int qrc = enqueue();
+                    const hipError_t endrc = hipStreamEndCapture(e->stream, &graph);
+                    ok = qrc == ORBHIP_OK && endrc == hipSuccess && graph != nullptr && key.generation == g_buffer_generation;
+                }
+                if (ok) ok = hipGraphInstantiate(&e->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess;
+                if (graph) (void)hipGraphDestroy(graph);
+                if (!ok) {
+                    (void)hipGetLastError();
+                    e->graph_exec = nullptr;
+                    e->graph_off = true;
+                } else {
+                    e->graph_key = key;
+                }
+            }
+            if (e->graph_exec) {
+                HIPCHK(hipGraphLaunch(e->graph_exec, e->stream));
+                e->last_batch = 1;
+                replayed = true;
+            }
+        }
+        if (!replayed && (rc = enqueue())) return rc;
         if ((rc = wait_and_collect_times(e))) return rc;
         const int herr = *(const int*)hblk;
         if (herr) {

@@ -105,6 +105,39 @@ def test_end_to_end(orb, orbref, synth, case):
     assert len(rkp) > 0
 
 
+def test_one_frame_per_call_replays_and_recaptures(orb, orbref, synth):
+    """One frame per call goes through a launch sequence captured once per image size and replayed: repeated
+    calls with different images, a change of image size, a batched call in between that reallocates the
+    handle's buffers, and a change of the Gaussian profile must each give the oracle's result."""
+    dev = orb.ORBextractor(800, 1.2, 8, 1, 20, device=0, max_width=752, max_height=480, max_batch=4)
+    ref = orbref.RefExtractor(800, 1.2, 8, 1, 20)
+
+    def check(img):
+        rkp, rdesc = ref(img)
+        dkp, ddesc = dev(img)
+        _assert_same(rkp, rdesc, dkp, ddesc)
+
+    for i in range(4):
+        check(synth.synth_image(640, 480, 40 + i))
+    check(synth.synth_image(752, 480, 50))  # new size: new capture
+    check(synth.synth_image(640, 480, 51))
+    imgs = synth.synth_batch(640, 480, 4, first_idx=60)  # larger arenas: the captured addresses are stale
+    outs = dev.extract_batch(imgs)
+    for img, (dkp, ddesc) in zip(imgs, outs):
+        rkp, rdesc = ref(img)
+        _assert_same(rkp, rdesc, dkp, ddesc)
+    for i in range(3):
+        check(synth.synth_image(640, 480, 70 + i))
+    dev.set_gaussian_profile(dev.GAUSS_SSE2)
+    orbref.lib().orbref_set_gauss_profile(1)
+    try:
+        check(synth.synth_image(640, 480, 80))
+    finally:
+        orbref.lib().orbref_set_gauss_profile(0)
+        dev.set_gaussian_profile(dev.GAUSS_SCALAR)
+    check(synth.synth_image(640, 480, 81))
+
+
 def test_batch_matches_single(orb, orbref, synth):
     w, h, nf = 640, 480, 1000
     dev, ref = _make(orb, orbref, w, h, nf, 8, 20, max_batch=4)
