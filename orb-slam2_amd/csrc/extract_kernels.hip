@@ -926,15 +926,16 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
     // the disc weight table and the test pattern are the same for every keypoint: one copy per
     // workgroup in LDS instead of a trip through the vector cache per keypoint
     __shared__ uint2 s_otab[31 * 8];
-    __shared__ uint4 s_pat[64];
+    // the 256 tests as floats (x0, y0, x1, y1), test 8 i + j of lane i at [32 j + i]: one conflict-free 16-byte read
+    // per test instead of byte reads and four conversions
+    __shared__ float4 s_patf[256];
     OD_T0
     // The tables go to LDS through registers, and the barrier that publishes them comes only after the slot record
     // and both windows have been requested: the three memory round trips of a workgroup (tables, record, windows)
     // would otherwise run one after the other, and a workgroup lives for little else.
     uint2 t_otab = make_uint2(0u, 0u);
-    uint4 t_pat = make_uint4(0u, 0u, 0u, 0u);
     if (threadIdx.x < 31 * 8) t_otab = ((const uint2*)otab)[threadIdx.x];
-    if (threadIdx.x < 64) t_pat = ((const uint4*)pattern)[threadIdx.x];
+    const uint32_t t_pat = ((const uint32_t*)pattern)[threadIdx.x];  // test threadIdx.x: four signed bytes
     int bx = blockIdx.x, f = blockIdx.y;
     xcd_frame_swizzle(bx, f, (int)gridDim.x, (int)gridDim.y);
     const int li = threadIdx.x % OD_LPK;
@@ -981,7 +982,9 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
         }
     }
     if (threadIdx.x < 31 * 8) s_otab[threadIdx.x] = t_otab;
-    if (threadIdx.x < 64) s_pat[threadIdx.x] = t_pat;
+    s_patf[32 * (threadIdx.x & 7) + (threadIdx.x >> 3)] =
+        make_float4((float)(int8_t)(t_pat & 0xffu), (float)(int8_t)((t_pat >> 8) & 0xffu), (float)(int8_t)((t_pat >> 16) & 0xffu),
+                    (float)(int8_t)(t_pat >> 24));
     __syncthreads();
     if (!active) return;
 
@@ -1020,17 +1023,25 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float angle = angle_deg * factorPI;
     const float a = orbtrig::cos_f<false>(angle), b = orbtrig::sin_f<false>(angle);
+    // cvRound of the rotated pattern coordinates without a conversion: t + 1.5 * 2^23 rounds t (|t| < 2^22) to the
+    // nearest integer, ties to even, exactly like cvRound's rint, and leaves 0x4B400000 + rint(t) in the float's bits;
+    // the low 24 bits (0x400000 + rint(t)) feed a 24-bit multiply-add, and the constants that ride along,
+    // 0x400000 * pitch + 0x4B400000, come off the window's base address once.
+    const float magic = 12582912.f;
+    const uint32_t pitch = 4 * DS_DWORDS;
     const uint8_t* center = (const uint8_t*)win + DS_REACH * (4 * DS_DWORDS) + DS_REACH + lead;
-    const int8_t* pat = (const int8_t*)s_pat + li * (32 * OD_BYTES);
+    const uint8_t* cbase = center - (0x400000u * pitch + 0x4B400000u);
+    static_assert(OD_BYTES == 1 && OD_LPK == 32, "the float pattern table is laid out for 8 tests per lane, 32 lanes per keypoint");
     uint32_t val = 0;
 #pragma unroll
     for (int j = 0; j < 8 * OD_BYTES; j++) {
-        const float x0 = (float)pat[4 * j], y0 = (float)pat[4 * j + 1], x1 = (float)pat[4 * j + 2], y1 = (float)pat[4 * j + 3];
-        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int v0 = center[r0 * (4 * DS_DWORDS) + c0], v1 = center[r1 * (4 * DS_DWORDS) + c1];
+        const float4 pt = s_patf[32 * j + li];
+        const float x0 = pt.x, y0 = pt.y, x1 = pt.z, y1 = pt.w;
+        const uint32_t r0 = __float_as_uint(__fadd_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)), magic));
+        const uint32_t c0 = __float_as_uint(__fadd_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)), magic));
+        const uint32_t r1 = __float_as_uint(__fadd_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)), magic));
+        const uint32_t c1 = __float_as_uint(__fadd_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)), magic));
+        const int v0 = cbase[__umul24(r0, pitch) + c0], v1 = cbase[__umul24(r1, pitch) + c1];
         val |= (uint32_t)(v0 < v1) << j;
     }
     OD_T(5)
