@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -31,7 +32,7 @@ inline uint32_t ordered_bits_to_float_bits(uint32_t u) { return (u & 0x80000000u
 
 // Bumped whenever a buffer of any handle is (re)allocated or released: a captured launch sequence holds raw
 // addresses and is only replayed while this is what it was at capture time.
-static unsigned long long g_buffer_generation = 0;
+static std::atomic<unsigned long long> g_buffer_generation{0};
 
 struct DeviceBuf {
     void* p = nullptr;
@@ -742,7 +743,7 @@ int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int batch, in
             // buffers first (nothing may be allocated while the stream is being captured)
             if ((rc = set_size(e, rows, cols, 1))) return rc;
             orbhip_extractor::GraphKey key;
-            key.rows = rows; key.cols = cols; key.cap = cap; key.tie_even = e->gauss_tie_even; key.generation = g_buffer_generation;
+            key.rows = rows; key.cols = cols; key.cap = cap; key.tie_even = e->gauss_tie_even; key.generation = g_buffer_generation.load();
             if (!e->graph_exec || !(key == e->graph_key)) {
                 if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
                 e->graph_exec = nullptr;
@@ -752,7 +753,7 @@ int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int batch, in
                 if (ok) {
                     const int qrc = enqueue();
                     const hipError_t endrc = hipStreamEndCapture(e->stream, &graph);
-                    ok = qrc == ORBHIP_OK && endrc == hipSuccess && graph != nullptr && key.generation == g_buffer_generation;
+                    ok = qrc == ORBHIP_OK && endrc == hipSuccess && graph != nullptr && key.generation == g_buffer_generation.load();
                 }
                 if (ok) ok = hipGraphInstantiate(&e->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess;
                 if (graph) (void)hipGraphDestroy(graph);
