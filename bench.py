@@ -235,6 +235,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="frames per GPU per step")
+    ap.add_argument("--max-batch", type=int, default=0,
+                    help="frames the extractor's arenas hold (default: the whole batch); smaller = the step runs as chunks of this size")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--features", type=int, default=1000)
@@ -280,7 +282,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    wl = ExtractWorkload(orb, torch, dev, args.width, args.height, args.features, args.batch, first_idx=rank * args.batch)
+    wl = ExtractWorkload(orb, torch, dev, args.width, args.height, args.features, args.batch, first_idx=rank * args.batch,
+                         max_batch=args.max_batch or None)
 
     for _ in range(args.warmup):
         wl.step()
