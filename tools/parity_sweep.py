@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on the GPU box: the HIP extractor and the Hamming scan against the CPU oracle on
-configurations drawn from a seeded generator, and the two windowed matchers on random frame pairs, for a time budget.  Everything is compared bit for bit (keypoint
+configurations drawn from a seeded generator, the two windowed matchers on random frame pairs and the five SearchByProjection overloads on reseeded scenes, for
+a time budget.  Everything is compared bit for bit (keypoint
 fields including the orientation's float bits, descriptors, kNN indices and distances).  Writes one JSON summary.
    python3 tools/parity_sweep.py [--seconds 240] [--seed 1] [--out gpurun_out/parity_sweep.json]
 A geometry whose cells reach past the border must be refused by both sides (the reference would read outside
@@ -67,6 +68,20 @@ def main():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import test_gpu_window as wt  # frame generators and the compare-with-the-oracle helpers of the tests
     INT_MAX = 2147483647
+    import test_gpu_projection as tp  # scenes, oracle calls and the device-against-oracle comparison of the tests
+    pj = {"calls": 0, "mismatching_calls": 0, "failures": []}  # SearchByProjection, all five overloads
+    real_default_rng = np.random.default_rng
+    real_run_device = tp.run_device
+
+    class ProjectionMismatch(Exception):
+        pass
+
+    def checked_run_device(*a, **k):
+        try:
+            return real_run_device(*a, **k)
+        except AssertionError as e:
+            raise ProjectionMismatch(str(e) or "device result differs from the oracle's")
+    tp.run_device = checked_run_device
     kinds = ["scene", "scene", "scene_flat", "noise", "smooth", "blocks"]
     last_print = time.time()
     while time.time() < t_end:
@@ -161,19 +176,39 @@ def main():
         except AssertionError as e:
             wm["mismatching_calls"] += 1
             wm["failures"].append(dict(w=ww, h=wh, levels=levels, ties=ties, cluster=cluster, ori=ori, sizes=sizes, what=str(e)[:200]))
+        # ---- the five SearchByProjection overloads: the scenes of tests/test_gpu_projection.py under fresh seeds ----
+        it_seed = int(rng.integers(0, 1 << 30))
+        np.random.default_rng = lambda seed=None, _s=it_seed: real_default_rng(None if seed is None else [int(seed), _s])
+        try:
+            for fn, kw in ((tp.test_local_map_overload, dict(th=float(rng.choice([1.0, 3.0])), ties=bool(rng.integers(0, 2)))),
+                           (tp.test_sim3_overload, dict(ties=bool(rng.integers(0, 2)))),
+                           (tp.test_frame_to_frame_overload, dict(window=int(rng.choice([15, 60])), ratio=float(rng.choice([0.8, 0.95])))),
+                           (tp.test_last_frame_overload, dict(th=float(rng.choice([7.0, 15.0])), ori=bool(rng.integers(0, 2)))),
+                           (tp.test_keyframe_overload, dict(orb_dist=int(rng.choice([64, 100])), ori=bool(rng.integers(0, 2))))):
+                pj["calls"] += 1
+                try:
+                    fn(orb, orbref, **kw)
+                except ProjectionMismatch as e:
+                    pj["mismatching_calls"] += 1
+                    pj["failures"].append(dict(test=fn.__name__, seed=it_seed, what=str(e)[:200], **kw))
+                except AssertionError:
+                    pass  # the tests' own "enough matches" checks are tuned to their fixed seeds, not parity statements
+        finally:
+            np.random.default_rng = real_default_rng
         if time.time() - last_print > 30:
             last_print = time.time()
             print("extraction: %d configurations, %d frames, %d mismatching; scans: %d calls, %d mismatching" %
                   (ex["configurations"], ex["frames"], ex["mismatching_frames"], kn["calls"], kn["mismatching_calls"]), flush=True)
     res = {"what": "tools/parity_sweep.py --seconds %g --seed %d: HIP path against the CPU oracle, bit for bit" % (args.seconds, args.seed),
-           "extraction": ex, "hamming_knn2": kn, "windowed_matchers": wm}
+           "extraction": ex, "hamming_knn2": kn, "windowed_matchers": wm, "search_by_projection": pj}
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, "w") as f:
         json.dump(res, f, indent=1)
     print(json.dumps({"extraction": {k: v for k, v in ex.items() if k != "failures"}, "failures": ex["failures"][:5],
                       "hamming_knn2": {k: v for k, v in kn.items() if k != "failures"}, "knn_failures": kn["failures"][:5],
-                      "windowed_matchers": {k: v for k, v in wm.items() if k != "failures"}, "window_failures": wm["failures"][:5]}))
-    return 1 if ex["mismatching_frames"] or kn["mismatching_calls"] or wm["mismatching_calls"] else 0
+                      "windowed_matchers": {k: v for k, v in wm.items() if k != "failures"}, "window_failures": wm["failures"][:5],
+                      "search_by_projection": {k: v for k, v in pj.items() if k != "failures"}, "projection_failures": pj["failures"][:5]}))
+    return 1 if ex["mismatching_frames"] or kn["mismatching_calls"] or wm["mismatching_calls"] or pj["mismatching_calls"] else 0
 
 
 if __name__ == "__main__":
