@@ -26,6 +26,12 @@ __device__ __forceinline__ int lane_prefix64(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
 }
 __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+// the key a given lane holds, to every lane (src is wave-uniform)
+__device__ __forceinline__ uint32_t lane_value(uint32_t x, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)x, src); }
+__device__ __forceinline__ uint64_t lane_value(uint64_t x, int src) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(x >> 32), src) << 32) |
+           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, src);
+}
 
 template <class KeyT>
 __device__ inline void wave_nth_element_desc(KeyT* v, int n, int nth, uint16_t* lpos, uint16_t* rpos, int lane,
@@ -44,9 +50,28 @@ __device__ inline void wave_nth_element_desc(KeyT* v, int n, int nth, uint16_t* 
         }
         --depth;
         const int mid = first + (last - first) / 2;
-        if (lane == 0) median_to(v, first, first + 1, mid, last - 1);
+        // median of v[first + 1], v[mid], v[last - 1] to v[first] (introselect.h: median_to): the four keys are read
+        // by four lanes at once and the decision is made on their broadcast values, so the pivot is known without
+        // another trip to LDS
+        const int p4 = lane == 0 ? first : lane == 1 ? first + 1 : lane == 2 ? mid : last - 1;
+        KeyT c4 = 0;
+        if (lane < 4) c4 = v[p4];
+        const KeyT vd = lane_value(c4, 0), va = lane_value(c4, 1), vb = lane_value(c4, 2), vc = lane_value(c4, 3);
+        int pm;
+        KeyT vm;
+        if (score_gt(va, vb)) {
+            if (score_gt(vb, vc)) pm = mid, vm = vb;
+            else if (score_gt(va, vc)) pm = last - 1, vm = vc;
+            else pm = first + 1, vm = va;
+        } else if (score_gt(va, vc)) pm = first + 1, vm = va;
+        else if (score_gt(vb, vc)) pm = last - 1, vm = vc;
+        else pm = mid, vm = vb;
+        if (lane == 0) {
+            v[first] = vm;
+            v[pm] = vd;
+        }
         wave_lds_fence();
-        const uint32_t ps = score_of(v[first]);
+        const uint32_t ps = score_of(vm);
         const int lo = first + 1, hi = last;
         int nL = 0, nR = 0;
         for (int base = lo; base < hi; base += 64) {
@@ -63,25 +88,38 @@ __device__ inline void wave_nth_element_desc(KeyT* v, int n, int nth, uint16_t* 
         }
         wave_lds_fence();
         const int mn = min(nL, nR);
-        int K = 0;
-        for (int base = 0; base < mn; base += 64) {
-            const int k = base + lane;
-            const bool sw = k < mn && lpos[k] < rpos[nR - 1 - k];
-            const int c = __popcll(__ballot(sw));
-            K += c;
-            if (c < 64) break;
+        // the first 64 (L[k], R[k]) pairs stay in registers: they decide K, are the pairs to swap and give the cut
+        int la = 0, rb = 0;
+        if (lane < nL) la = lpos[lane];
+        if (lane < nR) rb = rpos[nR - 1 - lane];
+        int K = __popcll(__ballot(lane < mn && la < rb));
+        if (K == 64) {
+            for (int base = 64; base < mn; base += 64) {
+                const int k = base + lane;
+                const bool sw = k < mn && lpos[k] < rpos[nR - 1 - k];
+                const int c = __popcll(__ballot(sw));
+                K += c;
+                if (c < 64) break;
+            }
         }
-        for (int k = lane; k < K; k += 64) {
+        if (lane < K) {
+            const KeyT ta = v[la], tb = v[rb];
+            v[la] = tb;
+            v[rb] = ta;
+        }
+        for (int k = 64 + lane; k < K; k += 64) {
             const int a = lpos[k], b = rpos[nR - 1 - k];
             const KeyT ta = v[a], tb = v[b];
             v[a] = tb;
             v[b] = ta;
         }
         int cut;
-        if (K == 0) cut = lpos[0];
-        else {
-            const int rk = rpos[nR - K];
-            cut = K < nL ? min((int)lpos[K], rk) : rk;
+        if (K == 0) {
+            cut = __builtin_amdgcn_readlane(la, 0);  // L[0]; nL >= 1: the scan always stops at the sentinel
+        } else {
+            const int rk = K <= 64 ? __builtin_amdgcn_readlane(rb, K - 1) : (int)rpos[nR - K];
+            const int lk = K < nL ? (K < 64 ? __builtin_amdgcn_readlane(la, K) : (int)lpos[K]) : rk;
+            cut = min(lk, rk);
         }
         cut = __builtin_amdgcn_readfirstlane(cut);
         wave_lds_fence();
