@@ -329,10 +329,19 @@ def main():
             "parity_frames_checked": len(ref_results), "parity_frames_mismatching": wl.mismatching(ref_results)}
 
     if not args.no_extra:
-        if use_dist:
-            legs = dist_legs(orb, torch, dist, dev, rank, world, barrier, max_over_ranks)
-        else:
-            legs = single_gpu_legs(orb, torch, dev, wl)
+        try:
+            if use_dist:
+                legs = dist_legs(orb, torch, dist, dev, rank, world, barrier, max_over_ranks)
+            else:
+                legs = single_gpu_legs(orb, torch, dev, wl)
+        except Exception as ex:  # a leg that raises must not lose the headline measurement either
+            dog.cancel()
+            if rank == 0:
+                out["extra"] = {"error": "a leg after the headline measurement raised %s: %s" % (type(ex).__name__, ex)}
+                print(json.dumps(out), flush=True)
+            sys.stderr.write("rank %d: %r\n" % (rank, ex))
+            sys.stderr.flush()
+            os._exit(0)  # no collective teardown: the other ranks may be anywhere
         if rank == 0:
             out["extra"] = legs
     barrier()
