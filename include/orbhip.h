@@ -340,6 +340,28 @@ int orbhip_search_by_projection(orbhip_matcher* m, const OrbProbe* probes, const
                                 const uint8_t* taken, int rule, float nnratio, int th_dist, int check_orientation,
                                 int32_t* match_of_feature, int32_t* nmatches);
 
+/* The search the reference's Fuse and SearchBySim3 make per projected map point — "match to the most similar
+ * keypoint in the radius" (ORBmatcher::Fuse src/ORBmatcher.cc:1096-1124 and :1225-1253, ORBmatcher::SearchBySim3
+ * :1376-1404 and :1461-1489): KeyFrame::GetFeaturesInArea(u, v, r) (src/KeyFrame.cc:638-683), the level test
+ * kpLevel in [min_level, max_level] of the probe, and the first candidate in list order with the least Hamming
+ * distance.  Unlike the SearchByProjection overloads the probes are independent (a feature can be the best of
+ * several probes; nothing is skipped), which is what these methods need: what they do with the result (Replace /
+ * AddObservation, the <= TH_LOW or <= TH_HIGH gate, the mutual-agreement check) stays host code in the
+ * reference's order.  Frame f: d_nprobes[f] probes at d_probes[f*probe_cap ...] with descriptors
+ * d_probe_desc[(f*probe_cap + i)*32 ...]; outputs (batch*probe_cap each) d_best_idx = bestIdx or -1 when the
+ * probe is not valid or no candidate passes the level test, d_best_dist = bestDist or INT_MAX.  Device pointers;
+ * asynchronous on the matcher's stream; no workspace, nothing read back. */
+int orbhip_best_in_radius_device(orbhip_matcher* m, const OrbProbe* d_probes, const uint8_t* d_probe_desc,
+                                 const int32_t* d_nprobes, int probe_cap, const OrbKeypoint* d_kp2, const uint8_t* d_desc2,
+                                 const int32_t* d_cell_start2, const int32_t* d_cell_items2, int batch, int cap,
+                                 OrbFrameBounds bounds, int32_t* d_best_idx, int32_t* d_best_dist);
+/* Host-pointer form for ONE keyframe (copy in, build its grid, search, copy out; blocking): what the forwarding
+ * bodies of ORBmatcher::Fuse (src/ORBmatcher.cc:1027-1145, :1147-1276) and ORBmatcher::SearchBySim3 (:1278-1516)
+ * call after they have projected their map points with the reference's own pose arithmetic. */
+int orbhip_best_in_radius(orbhip_matcher* m, const OrbProbe* probes, const uint8_t* probe_desc, int nprobes,
+                          const OrbKeypoint* kp2, const uint8_t* desc2, int n2, OrbFrameBounds bounds, int32_t* best_idx,
+                          int32_t* best_dist);
+
 /* Host-pointer forms of the two matchers for ONE frame pair (copy in, build F2's grid, match, copy
  * out; blocking) — what a forwarding ORBmatcher::SearchForInitialization / WindowSearch calls with
  * the contents of F1.mvKeysUn / mDescriptors and F2's. */

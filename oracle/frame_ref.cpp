@@ -748,6 +748,236 @@ int orbref_sbp_keyframe(const void* kp_cur, const uint8_t* desc_cur, int n_cur, 
     return nmatches;
 }
 
+// ---------------------------------------------------------------------------------------------
+// ORBmatcher::Fuse (both forms) and ORBmatcher::SearchBySim3: per projected map point the most similar keypoint
+// in the radius, with no interaction between map points.  What the reference then does with a match (Replace /
+// AddObservation / AddMapPoint, src/ORBmatcher.cc:1127-1141, :1256-1270) touches only the map and stays with the
+// caller; the functions below return bestIdx / bestDist per map point and the count the reference returns.
+namespace {
+
+// R (3x3 row-major) * x + t through cv::gemm's small-matrix path, as rigid() above
+void rigid9(const float* R, const float* t, const float* x, float out[3]) {
+    for (int i = 0; i < 3; i++) {
+        const float* a = R + 3 * i;
+        float t0 = a[0] * x[0] + a[1] * x[1] + a[2] * x[2];
+        out[i] = (float)(t0 * 1.0 + t[i] * 1.0);
+    }
+}
+
+// the loop body shared by :1054-1124, :1180-1253, :1340-1404 and :1423-1489 from "Depth must be positive" on:
+// p3Dc = the point in the camera of KF, PO / normal = the viewing-angle test (normal == nullptr: SearchBySim3 has
+// none), dist3D = the distance the scale prediction uses.  Returns false where the reference takes a `continue`
+// before its scan; bestIdx stays -1 / bestDist INT_MAX when the scan finds nothing.
+bool best_in_radius(FrameRef& KF, const uint8_t* desc, float fx, float fy, float cx, float cy, const float* vfScaleFactors,
+                    int nlevels, const float p3Dc[3], bool double_invz, float dist3D, const float* PO, const float* normal,
+                    float minDistance, float maxDistance, float th, const uint8_t* dMP, int& bestIdx, int& bestDist,
+                    ProbeRec* q) {
+    const int nMaxLevel = nlevels - 1;
+    if (p3Dc[2] < 0.0f) return false;
+    // :1061 "1/z" in float, :1190 / :1348 / :1431 "1.0/z" in double then stored to float: the same float (a
+    // quotient of two floats rounded through double and then to float is the correctly rounded float quotient)
+    const float invz = double_invz ? (float)(1.0 / p3Dc[2]) : 1 / p3Dc[2];
+    const float x = p3Dc[0] * invz;
+    const float y = p3Dc[1] * invz;
+    const float u = fx * x + cx;
+    const float v = fy * y + cy;
+    if (!(u >= KF.mnMinX && u < KF.mnMaxX && v >= KF.mnMinY && v < KF.mnMaxY)) return false;  // KeyFrame::IsInImage, src/KeyFrame.cc:680-683
+    if (dist3D < minDistance || dist3D > maxDistance) return false;
+    if (normal && dot3(PO, normal) < 0.5 * dist3D) return false;
+    const float ratio = dist3D / minDistance;
+    const float* it = std::lower_bound(vfScaleFactors, vfScaleFactors + nlevels, ratio);
+    const int nPredictedLevel = std::min(static_cast<int>(it - vfScaleFactors), nMaxLevel);
+    const float radius = th * vfScaleFactors[nPredictedLevel];
+    if (q) {
+        q->u = u;
+        q->v = v;
+        q->r = radius;
+        q->min_level = nPredictedLevel - 1;
+        q->max_level = nPredictedLevel;
+        q->valid = 1;
+    }
+    std::vector<size_t> vIndices = KF.GetFeaturesInArea(u, v, radius, -1, -1);  // KeyFrame::GetFeaturesInArea, src/KeyFrame.cc:638-678
+    if (vIndices.empty()) return false;
+    for (size_t idx : vIndices) {
+        const int kpLevel = KF.kp[idx].octave;
+        if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+        const int dist = orbref_hamming(dMP, desc + idx * 32);
+        if (dist < bestDist) {
+            bestDist = dist;
+            bestIdx = (int)idx;
+        }
+    }
+    return true;
+}
+
+}  // namespace
+
+// Fuse(KeyFrame *pKF, vector<MapPoint *> &vpMapPoints, float th), src/ORBmatcher.cc:1027-1145.  skip[i]: the map point
+// is NULL, isBad() or IsInKeyFrame(pKF).  Tcw: the keyframe's pose (GetRotation / GetTranslation; its camera centre
+// Ow = -Rcw.t()*tcw, src/KeyFrame.cc:108).  Returns nFused; best_idx / best_dist per map point (-1 / INT_MAX where
+// the scan did not run or found nothing).
+int orbref_fuse_pose(const void* kp, const uint8_t* desc, int n, const int32_t bounds[4], float fx, float fy, float cx, float cy,
+                     const float* vfScaleFactors, int nlevels, const float* Tcw /*4x4 row-major*/, int npoints,
+                     const uint8_t* skip, const float* pos, const float* normal, const float* minDistArr,
+                     const float* maxDistArr, const uint8_t* mp_desc, float th, int32_t* best_idx, int32_t* best_dist,
+                     void* probes_out) {
+    FrameRef KF(kp, desc, n, bounds);
+    ProbeRec* pr = (ProbeRec*)probes_out;
+    float Rcw[9], tcw[3], Ow[3];
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) Rcw[3 * i + j] = Tcw[4 * i + j];
+        tcw[i] = Tcw[4 * i + 3];
+    }
+    centre(Rcw, tcw, Ow);
+    int nFused = 0;
+    for (int i = 0; i < npoints; i++) {
+        clear_probe(pr ? pr + i : nullptr);
+        best_idx[i] = -1;
+        best_dist[i] = INT_MAX;
+        if (skip[i]) continue;
+        const float* p3Dw = pos + 3 * i;
+        float p3Dc[3];
+        rigid9(Rcw, tcw, p3Dw, p3Dc);
+        float PO[3] = {p3Dw[0] - Ow[0], p3Dw[1] - Ow[1], p3Dw[2] - Ow[2]};
+        const float dist3D = norm3(PO);
+        int bestDist = INT_MAX, bestIdx = -1;
+        if (!best_in_radius(KF, desc, fx, fy, cx, cy, vfScaleFactors, nlevels, p3Dc, false, dist3D, PO, normal + 3 * i,
+                            minDistArr[i], maxDistArr[i], th, mp_desc + (size_t)i * 32, bestIdx, bestDist, pr ? pr + i : nullptr))
+            continue;
+        best_idx[i] = bestIdx;
+        best_dist[i] = bestDist;
+        if (bestDist <= TH_LOW) nFused++;
+    }
+    return nFused;
+}
+
+// Fuse(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint *> &vpPoints, float th), src/ORBmatcher.cc:1147-1276.
+// skip[i]: isBad() or in spAlreadyFound.
+int orbref_fuse_sim3(const void* kp, const uint8_t* desc, int n, const int32_t bounds[4], float fx, float fy, float cx, float cy,
+                     const float* vfScaleFactors, int nlevels, const float* Scw /*4x4 row-major*/, int npoints,
+                     const uint8_t* skip, const float* pos, const float* normal, const float* minDistArr,
+                     const float* maxDistArr, const uint8_t* mp_desc, float th, int32_t* best_idx, int32_t* best_dist,
+                     void* probes_out) {
+    FrameRef KF(kp, desc, n, bounds);
+    ProbeRec* pr = (ProbeRec*)probes_out;
+    // Decompose Scw
+    float sR[9], Rcw[9], tcw[3], Ow[3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) sR[3 * i + j] = Scw[4 * i + j];
+    const float scw = std::sqrt(dot3(sR, sR));
+    const float inv = (float)(1. / scw);
+    for (int i = 0; i < 9; i++) Rcw[i] = sR[i] * inv;
+    for (int i = 0; i < 3; i++) tcw[i] = Scw[4 * i + 3] * inv;
+    centre(Rcw, tcw, Ow);
+    int nFused = 0;
+    for (int iMP = 0; iMP < npoints; iMP++) {
+        clear_probe(pr ? pr + iMP : nullptr);
+        best_idx[iMP] = -1;
+        best_dist[iMP] = INT_MAX;
+        if (skip[iMP]) continue;
+        const float* p3Dw = pos + 3 * iMP;
+        float p3Dc[3];
+        rigid9(Rcw, tcw, p3Dw, p3Dc);
+        float PO[3] = {p3Dw[0] - Ow[0], p3Dw[1] - Ow[1], p3Dw[2] - Ow[2]};
+        const float dist3D = norm3(PO);
+        int bestDist = INT_MAX, bestIdx = -1;
+        if (!best_in_radius(KF, desc, fx, fy, cx, cy, vfScaleFactors, nlevels, p3Dc, true, dist3D, PO, normal + 3 * iMP,
+                            minDistArr[iMP], maxDistArr[iMP], th, mp_desc + (size_t)iMP * 32, bestIdx, bestDist,
+                            pr ? pr + iMP : nullptr))
+            continue;
+        best_idx[iMP] = bestIdx;
+        best_dist[iMP] = bestDist;
+        if (bestDist <= TH_LOW) nFused++;
+    }
+    return nFused;
+}
+
+// SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12, const float &s12, const cv::Mat &R12,
+// const cv::Mat &t12, float th), src/ORBmatcher.cc:1278-1516.  skip1[i1]: pKF1's map point is NULL, bad or
+// vbAlreadyMatched1[i1]; skip2[i2] likewise with vbAlreadyMatched2.  Both projections use pKF1's intrinsics
+// (:1281-1284).  Outputs: vnMatch1 (n1), vnMatch2 (n2), matches12[i1] = idx2 for the pairs that agree (:1500-1513)
+// else -1; returns nFound.
+int orbref_search_by_sim3(const void* kp1, const uint8_t* desc1, int n1, const void* kp2, const uint8_t* desc2, int n2,
+                          const int32_t bounds[4], float fx, float fy, float cx, float cy, const float* vfScaleFactors1,
+                          int nlevels1, const float* vfScaleFactors2, int nlevels2, const float* T1w, const float* T2w,
+                          float s12, const float* R12 /*9*/, const float* t12 /*3*/, float th, const uint8_t* skip1,
+                          const float* pos1, const float* minDist1, const float* maxDist1, const uint8_t* mp_desc1,
+                          const uint8_t* skip2, const float* pos2, const float* minDist2, const float* maxDist2,
+                          const uint8_t* mp_desc2, int32_t* vnMatch1, int32_t* vnMatch2, int32_t* matches12, void* probes1_out,
+                          void* probes2_out) {
+    FrameRef KF1(kp1, desc1, n1, bounds), KF2(kp2, desc2, n2, bounds);
+    ProbeRec* pr1 = (ProbeRec*)probes1_out;
+    ProbeRec* pr2 = (ProbeRec*)probes2_out;
+    float R1w[9], t1w[3], R2w[9], t2w[3];
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) {
+            R1w[3 * i + j] = T1w[4 * i + j];
+            R2w[3 * i + j] = T2w[4 * i + j];
+        }
+        t1w[i] = T1w[4 * i + 3];
+        t2w[i] = T2w[4 * i + 3];
+    }
+    // sR12 = s12*R12, sR21 = (1.0/s12)*R12.t(): elementwise float products with (float)alpha; t21 = -sR21*t12: one
+    // cv::gemm through the small-matrix path with alpha = -1
+    float sR12[9], sR21[9], t21[3];
+    const float a12 = (float)(double)s12, a21 = (float)(1.0 / s12);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            sR12[3 * i + j] = R12[3 * i + j] * a12;
+            sR21[3 * i + j] = R12[3 * j + i] * a21;
+        }
+    for (int i = 0; i < 3; i++) {
+        const float* a = sR21 + 3 * i;
+        float t0 = a[0] * t12[0] + a[1] * t12[1] + a[2] * t12[2];
+        t21[i] = (float)(t0 * -1.0);
+    }
+    for (int i = 0; i < n1; i++) vnMatch1[i] = -1;
+    for (int i = 0; i < n2; i++) vnMatch2[i] = -1;
+    // Transform from KF1 to KF2 and search
+    for (int i1 = 0; i1 < n1; i1++) {
+        clear_probe(pr1 ? pr1 + i1 : nullptr);
+        if (skip1[i1]) continue;
+        float p3Dc1[3], p3Dc2[3];
+        rigid9(R1w, t1w, pos1 + 3 * i1, p3Dc1);
+        rigid9(sR21, t21, p3Dc1, p3Dc2);
+        const float dist3D = norm3(p3Dc2);
+        int bestDist = INT_MAX, bestIdx = -1;
+        if (!best_in_radius(KF2, desc2, fx, fy, cx, cy, vfScaleFactors2, nlevels2, p3Dc2, true, dist3D, nullptr, nullptr,
+                            minDist1[i1], maxDist1[i1], th, mp_desc1 + (size_t)i1 * 32, bestIdx, bestDist, pr1 ? pr1 + i1 : nullptr))
+            continue;
+        if (bestDist <= TH_HIGH) vnMatch1[i1] = bestIdx;
+    }
+    // Transform from KF2 to KF1 and search
+    for (int i2 = 0; i2 < n2; i2++) {
+        clear_probe(pr2 ? pr2 + i2 : nullptr);
+        if (skip2[i2]) continue;
+        float p3Dc2[3], p3Dc1[3];
+        rigid9(R2w, t2w, pos2 + 3 * i2, p3Dc2);
+        rigid9(sR12, t12, p3Dc2, p3Dc1);
+        const float dist3D = norm3(p3Dc1);
+        int bestDist = INT_MAX, bestIdx = -1;
+        if (!best_in_radius(KF1, desc1, fx, fy, cx, cy, vfScaleFactors1, nlevels1, p3Dc1, true, dist3D, nullptr, nullptr,
+                            minDist2[i2], maxDist2[i2], th, mp_desc2 + (size_t)i2 * 32, bestIdx, bestDist, pr2 ? pr2 + i2 : nullptr))
+            continue;
+        if (bestDist <= TH_HIGH) vnMatch2[i2] = bestIdx;
+    }
+    // Check agreement
+    int nFound = 0;
+    for (int i1 = 0; i1 < n1; i1++) {
+        matches12[i1] = -1;
+        int idx2 = vnMatch1[i1];
+        if (idx2 >= 0) {
+            int idx1 = vnMatch2[idx2];
+            if (idx1 == i1) {
+                matches12[i1] = idx2;
+                nFound++;
+            }
+        }
+    }
+    return nFound;
+}
+
+
 
 // ---------------------------------------------------------------------------------------------
 // cv::undistortPoints(src, dst, cameraMatrix, distCoeffs, R = Mat(), P = cameraMatrix) as OpenCV 2.4's

@@ -99,6 +99,11 @@ def lib():
         L.orbref_sbp_last_frame.argtypes = [vp, vp, i32, vp, vp, f32, f32, f32, f32, vp, vp, vp, vp, i32, vp, vp, f32, i32, vp, vp]
         L.orbref_sbp_keyframe.argtypes = [vp, vp, i32, vp, vp, f32, f32, f32, f32, vp, vp, i32, i32, vp, vp, vp, vp, vp, f32,
                                           i32, i32, vp, vp]
+        fuse_args = [vp, vp, i32, vp, f32, f32, f32, f32, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp]
+        L.orbref_fuse_pose.argtypes = fuse_args
+        L.orbref_fuse_sim3.argtypes = fuse_args
+        L.orbref_search_by_sim3.argtypes = [vp, vp, i32, vp, vp, i32, vp, f32, f32, f32, f32, vp, i32, vp, i32, vp, vp, f32, vp, vp,
+                                            f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -304,6 +309,46 @@ def sbp_sim3(kp, desc, bounds, K, scale_factors, Scw, matched, skip, pos, normal
     n = lib().orbref_sbp_sim3(_p(kp), _p(desc), len(kp), _p(b), K[0], K[1], K[2], K[3], _p(sf), len(sf), _p(S), _p(mt), npts,
                               *[_p(a) for a in args], int(th), _p(out), _p(probes))
     return n, out[:len(kp)].copy(), probes[:npts].copy()
+
+
+def fuse(kp, desc, bounds, K, scale_factors, T, skip, pos, normal, min_dist, max_dist, mp_desc, th, sim3=False):
+    """Fuse(KeyFrame*, vector<MapPoint*>&, th) (T = the keyframe's Tcw) or, with sim3=True, Fuse(KeyFrame*, Scw,
+    vpPoints, th) (T = Scw): (nFused, best_idx, best_dist, probes) per map point."""
+    kp, desc = _frame(kp, desc)
+    npts = len(skip)
+    bi = np.zeros(max(npts, 1), np.int32)
+    bd = np.zeros(max(npts, 1), np.int32)
+    probes = np.zeros(max(npts, 1), PROBE_DTYPE)
+    sf, b, Tm = _f32(scale_factors), _bounds(bounds), _f32(T).reshape(16)
+    args = [_u8(skip, npts), _f32(pos), _f32(normal), _f32(min_dist), _f32(max_dist), np.ascontiguousarray(mp_desc, dtype=np.uint8)]
+    f = lib().orbref_fuse_sim3 if sim3 else lib().orbref_fuse_pose
+    n = f(_p(kp), _p(desc), len(kp), _p(b), K[0], K[1], K[2], K[3], _p(sf), len(sf), _p(Tm), npts, *[_p(a) for a in args],
+          float(th), _p(bi), _p(bd), _p(probes))
+    return n, bi[:npts].copy(), bd[:npts].copy(), probes[:npts].copy()
+
+
+def search_by_sim3(kp1, desc1, kp2, desc2, bounds, K, scale_factors, T1w, T2w, s12, R12, t12, th, skip1, pos1, min1, max1,
+                   mp_desc1, skip2, pos2, min2, max2, mp_desc2):
+    """SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th): (nFound, matches12 [n1], vnMatch1 [n1], vnMatch2 [n2],
+    probes1 [n1], probes2 [n2])."""
+    kp1, desc1 = _frame(kp1, desc1)
+    kp2, desc2 = _frame(kp2, desc2)
+    n1, n2 = len(kp1), len(kp2)
+    assert len(skip1) == n1 and len(skip2) == n2
+    m1 = np.zeros(max(n1, 1), np.int32)
+    m2 = np.zeros(max(n2, 1), np.int32)
+    m12 = np.zeros(max(n1, 1), np.int32)
+    pr1 = np.zeros(max(n1, 1), PROBE_DTYPE)
+    pr2 = np.zeros(max(n2, 1), PROBE_DTYPE)
+    sf, b = _f32(scale_factors), _bounds(bounds)
+    A = [_f32(T1w).reshape(16), _f32(T2w).reshape(16)]
+    R, t = _f32(R12).reshape(9), _f32(t12).reshape(3)
+    side1 = [_u8(skip1, n1), _f32(pos1), _f32(min1), _f32(max1), np.ascontiguousarray(mp_desc1, dtype=np.uint8)]
+    side2 = [_u8(skip2, n2), _f32(pos2), _f32(min2), _f32(max2), np.ascontiguousarray(mp_desc2, dtype=np.uint8)]
+    n = lib().orbref_search_by_sim3(_p(kp1), _p(desc1), n1, _p(kp2), _p(desc2), n2, _p(b), K[0], K[1], K[2], K[3], _p(sf), len(sf),
+                                    _p(sf), len(sf), _p(A[0]), _p(A[1]), float(s12), _p(R), _p(t), float(th),
+                                    *[_p(a) for a in side1], *[_p(a) for a in side2], _p(m1), _p(m2), _p(m12), _p(pr1), _p(pr2))
+    return n, m12[:n1].copy(), m1[:n1].copy(), m2[:n2].copy(), pr1[:n1].copy(), pr2[:n2].copy()
 
 
 def sbp_frames(kp1, desc1, skip1, pos1, Tc2w, K, kp2, desc2, bounds, taken2, window_size, nnratio):

@@ -379,6 +379,51 @@ __global__ __launch_bounds__(256) void k_area_fill(QuerySource s, const KpDev* _
     }
 }
 
+// "Match to the most similar keypoint in the radius" (src/ORBmatcher.cc:1105-1124, :1234-1253, :1384-1404,
+// :1469-1489): per probe the first feature, in GetFeaturesInArea order, that attains the least distance.  The
+// probes of these methods (Fuse, SearchBySim3) do not interact — no feature is taken away by an earlier probe —
+// so sixteen lanes enumerate one probe's area, keep their own least (distance, position, index) key and the
+// group reduces it; no candidate lists are stored.
+__global__ __launch_bounds__(256) void k_best_in_radius(QuerySource s, const KpDev* __restrict__ kp2,
+                                                        const int32_t* __restrict__ cell_start,
+                                                        const int32_t* __restrict__ cell_items, int cap2, GridGeom gg,
+                                                        const uint8_t* __restrict__ desc1, const uint8_t* __restrict__ desc2,
+                                                        int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist) {
+    const int i = (blockIdx.x * 256 + threadIdx.x) / AREA_LPQ, li = threadIdx.x % AREA_LPQ, f = blockIdx.y;
+    AreaQuery q;
+    q.active = false;
+    q.x = q.y = q.r = 0.f;
+    q.min_level = q.max_level = -1;
+    if (i < s.nq) q = make_query(s, f, i);
+    uint4 d1a = make_uint4(0, 0, 0, 0), d1b = d1a;
+    if (q.active) {
+        const uint4* d1 = (const uint4*)(desc1 + ((long long)f * s.nq + i) * 32);
+        d1a = d1[0];
+        d1b = d1[1];
+    }
+    const uint8_t* d2f = desc2 + (long long)f * cap2 * 32;
+    unsigned long long key = ~0ull;  // distance | position in the list | feature index
+    area_group<true>(gg, kp2 + (long long)f * cap2, cell_start + (long long)f * (GRID_CELLS + 1), cell_items + (long long)f * cap2, q,
+                     li, 0, [&](int i2, int pos) {
+                         const uint4* t = (const uint4*)(d2f + (long long)i2 * 32);
+                         const uint4 a = t[0], b = t[1];
+                         const int dist = __popc(a.x ^ d1a.x) + __popc(a.y ^ d1a.y) + __popc(a.z ^ d1a.z) + __popc(a.w ^ d1a.w) +
+                                          __popc(b.x ^ d1b.x) + __popc(b.y ^ d1b.y) + __popc(b.z ^ d1b.z) + __popc(b.w ^ d1b.w);
+                         const unsigned long long k = ((unsigned long long)dist << 32) | ((unsigned long long)pos << 16) | (unsigned)i2;
+                         key = k < key ? k : key;
+                     });
+#pragma unroll
+    for (int o = AREA_LPQ / 2; o >= 1; o >>= 1) {
+        const unsigned long long other = __shfl_xor(key, o);
+        key = other < key ? other : key;
+    }
+    if (i < s.nq && li == 0) {
+        const long long at = (long long)f * s.nq + i;
+        best_idx[at] = key == ~0ull ? -1 : (int32_t)(key & 0xffffu);
+        best_dist[at] = key == ~0ull ? INT_MAX : (int32_t)(key >> 32);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Resolution: one wave per frame pair.
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
@@ -1039,6 +1084,39 @@ int orbhip_search_by_projection_device(orbhip_matcher* m, const OrbProbe* d_prob
     return ORBHIP_OK;
 }
 
+int orbhip_best_in_radius_device(orbhip_matcher* m, const OrbProbe* d_probes, const uint8_t* d_probe_desc,
+                                 const int32_t* d_nprobes, int probe_cap, const OrbKeypoint* d_kp2, const uint8_t* d_desc2,
+                                 const int32_t* d_cell_start2, const int32_t* d_cell_items2, int batch, int cap,
+                                 OrbFrameBounds bounds, int32_t* d_best_idx, int32_t* d_best_dist) {
+    int rc = check_frames(m, batch, cap, bounds);
+    if (rc) return rc;
+    if (probe_cap < 1 || probe_cap > (1 << 22)) return orb_fail(ORBHIP_ECAP, "probe_cap %d outside 1..%d", probe_cap, 1 << 22);
+    if (batch == 0) return ORBHIP_OK;
+    if (!d_probes || !d_probe_desc || !d_nprobes || !d_kp2 || !d_desc2 || !d_cell_start2 || !d_cell_items2 || !d_best_idx ||
+        !d_best_dist)
+        return orb_fail(ORBHIP_EINVAL, "null buffer");
+    HIPCHK(hipSetDevice(m->device));
+    (void)hipGetLastError();
+    QuerySource s;
+    s.mode = MODE_PROBE;
+    s.queries = nullptr;
+    s.probes = d_probes;
+    s.kp1 = nullptr;
+    s.n1 = d_nprobes;
+    s.prev = nullptr;
+    s.valid1 = nullptr;
+    s.r = 0.f;
+    s.min_level = s.max_level = -1;
+    s.nq = probe_cap;
+    HIPCHK(hipEventRecord(m->ev0, m->stream));
+    dim3 qgrid((unsigned)(((long long)probe_cap * AREA_LPQ + 255) / 256), batch);
+    hipLaunchKernelGGL(k_best_in_radius, qgrid, dim3(256), 0, m->stream, s, (const KpDev*)d_kp2, d_cell_start2, d_cell_items2, cap,
+                       make_geom(bounds), d_probe_desc, d_desc2, d_best_idx, d_best_dist);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(m->ev1, m->stream));
+    return ORBHIP_OK;
+}
+
 }  // extern "C"
 
 namespace {
@@ -1219,6 +1297,61 @@ int orbhip_search_by_projection(orbhip_matcher* m, const OrbProbe* probes, const
     HIPCHK(hipStreamSynchronize(m->stream));  // the device forms do not wait when a reservation is in place
     if (n2) HIPCHK(hipMemcpy(match_of_feature, b + o_m, sizeof(int32_t) * n2, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(nmatches, b + o_nm, sizeof(int32_t), hipMemcpyDeviceToHost));
+    return ORBHIP_OK;
+}
+
+int orbhip_best_in_radius(orbhip_matcher* m, const OrbProbe* probes, const uint8_t* probe_desc, int nprobes,
+                          const OrbKeypoint* kp2, const uint8_t* desc2, int n2, OrbFrameBounds bounds, int32_t* best_idx,
+                          int32_t* best_dist) {
+    if (!m) return orb_fail(ORBHIP_EINVAL, "null matcher");
+    if (nprobes < 0 || n2 < 0) return orb_fail(ORBHIP_EINVAL, "negative size");
+    if ((nprobes && (!probes || !probe_desc || !best_idx || !best_dist)) || (n2 && (!kp2 || !desc2)))
+        return orb_fail(ORBHIP_EINVAL, "null buffer");
+    if (nprobes == 0) return ORBHIP_OK;
+    const int cap = std::max(1, n2), pcap = nprobes;
+    int rc = check_frames(m, 1, cap, bounds);
+    if (rc) return rc;
+    if (pcap > (1 << 22)) return orb_fail(ORBHIP_ECAP, "%d probes > %d", nprobes, 1 << 22);
+    HIPCHK(hipSetDevice(m->device));
+    // staging: probes | probe descriptors | keypoints | descriptors | n[2] | grid | best index | best distance
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off += align256(bytes);
+        return o;
+    };
+    const size_t o_pr = take(sizeof(OrbProbe) * pcap), o_pd = take(32 * (size_t)pcap), o_kp = take(sizeof(OrbKeypoint) * cap);
+    const size_t o_d = take(32 * (size_t)cap), o_n = take(sizeof(int32_t) * 2);
+    const size_t o_cs = take(sizeof(int32_t) * (GRID_CELLS + 1)), o_ci = take(sizeof(int32_t) * cap);
+    const size_t o_bi = take(sizeof(int32_t) * pcap), o_bd = take(sizeof(int32_t) * pcap);
+    if (off > m->stage_bytes) {
+        if (m->d_stage) hipFree(m->d_stage);
+        m->d_stage = nullptr;
+        m->stage_bytes = 0;
+        if (hipMalloc(&m->d_stage, off) != hipSuccess) return orb_fail(ORBHIP_ENOMEM, "hipMalloc of %zu bytes failed", off);
+        m->stage_bytes = off;
+    }
+    char* b = (char*)m->d_stage;
+    const int32_t n[2] = {nprobes, n2};
+    HIPCHK(hipMemcpyAsync(b + o_n, n, sizeof(n), hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(b + o_pr, probes, sizeof(OrbProbe) * nprobes, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(b + o_pd, probe_desc, 32 * (size_t)nprobes, hipMemcpyHostToDevice, m->stream));
+    if (n2) {
+        HIPCHK(hipMemcpyAsync(b + o_kp, kp2, sizeof(OrbKeypoint) * n2, hipMemcpyHostToDevice, m->stream));
+        HIPCHK(hipMemcpyAsync(b + o_d, desc2, 32 * (size_t)n2, hipMemcpyHostToDevice, m->stream));
+    }
+    HIPCHK(hipStreamSynchronize(m->stream));  // n[] lives on this stack frame
+    if ((rc = orbhip_frame_grid_device(m, (const OrbKeypoint*)(b + o_kp), (const int32_t*)(b + o_n) + 1, 1, cap, bounds,
+                                       (int32_t*)(b + o_cs), (int32_t*)(b + o_ci))))
+        return rc;
+    if ((rc = orbhip_best_in_radius_device(m, (const OrbProbe*)(b + o_pr), (const uint8_t*)(b + o_pd), (const int32_t*)(b + o_n),
+                                           pcap, (const OrbKeypoint*)(b + o_kp), (const uint8_t*)(b + o_d),
+                                           (const int32_t*)(b + o_cs), (const int32_t*)(b + o_ci), 1, cap, bounds,
+                                           (int32_t*)(b + o_bi), (int32_t*)(b + o_bd))))
+        return rc;
+    HIPCHK(hipMemcpyAsync(best_idx, b + o_bi, sizeof(int32_t) * nprobes, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(best_dist, b + o_bd, sizeof(int32_t) * nprobes, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
     return ORBHIP_OK;
 }
 

@@ -193,6 +193,43 @@ class ORBmatcher:
         self._end()
         return nm, out
 
+    def BestInRadius(self, F, probes, probe_desc, nprobes):
+        """The per-map-point search of ORBmatcher::Fuse (src/ORBmatcher.cc:1096-1124, :1225-1253) and
+        ORBmatcher::SearchBySim3 (:1376-1404, :1461-1489) on a batch of keyframes: GetFeaturesInArea(u, v, r), the
+        level test of the probe and the first candidate with the least distance; probes are independent.
+        Arguments as for SearchByProjection.  Returns (best_idx [batch, probe_cap]: bestIdx or -1,
+        best_dist [batch, probe_cap]: bestDist or INT_MAX)."""
+        import torch
+        assert probes.is_cuda and probes.dtype == torch.uint8 and probes.is_contiguous() and probes.shape[-1] == 32
+        assert probe_desc.is_cuda and probe_desc.dtype == torch.uint8 and probe_desc.is_contiguous()
+        assert probes.shape[0] == F.batch and probe_desc.shape[:2] == probes.shape[:2]
+        assert nprobes.is_cuda and nprobes.dtype == torch.int32
+        dev = F.n.device
+        pcap = int(probes.shape[1])
+        best_idx = torch.empty((F.batch, pcap), dtype=torch.int32, device=dev)
+        best_dist = torch.empty((F.batch, pcap), dtype=torch.int32, device=dev)
+        self._begin()
+        _lib.check(self._L.orbhip_best_in_radius_device(
+            self._h, probes.data_ptr(), probe_desc.data_ptr(), nprobes.data_ptr(), pcap, F.kp.data_ptr(), F.desc.data_ptr(),
+            F.cell_start.data_ptr(), F.cell_items.data_ptr(), F.batch, F.cap, F.bounds, best_idx.data_ptr(), best_dist.data_ptr()))
+        self._end()
+        return best_idx, best_dist
+
+    def best_in_radius_host(self, probes, probe_desc, kp2, desc2, bounds):
+        """One keyframe from host arrays (what the forwarding ORBmatcher::Fuse / SearchBySim3 call after projecting
+        their map points).  Returns (best_idx, best_dist) per probe."""
+        from .extractor import KP_DTYPE
+        from .frame import PROBE_DTYPE
+        probes = np.ascontiguousarray(probes, dtype=PROBE_DTYPE)
+        probe_desc = np.ascontiguousarray(probe_desc, dtype=np.uint8).reshape(-1, 32)
+        kp2 = np.ascontiguousarray(kp2, dtype=KP_DTYPE)
+        desc2 = np.ascontiguousarray(desc2, dtype=np.uint8).reshape(-1, 32)
+        bi = np.full(max(len(probes), 1), -1, np.int32)
+        bd = np.full(max(len(probes), 1), INT_MAX, np.int32)
+        _lib.check(self._L.orbhip_best_in_radius(self._h, _p(probes), _p(probe_desc), len(probes), _p(kp2), _p(desc2), len(kp2),
+                                                 _lib.OrbFrameBounds(*map(int, bounds)), _p(bi), _p(bd)))
+        return bi[:len(probes)].copy(), bd[:len(probes)].copy()
+
     def search_by_projection_host(self, probes, probe_desc, kp2, desc2, bounds, rule, taken=None, th_dist=TH_HIGH,
                                   check_orientation=None):
         """One target frame from host arrays (what a forwarding ORBmatcher::SearchByProjection does after

@@ -1,8 +1,8 @@
 // The accelerated primitive of the reference's ORBmatcher, with its signature unchanged:
 //   static int ORBmatcher::DescriptorDistance(const cv::Mat &a, const cv::Mat &b)
 // (include/ORBmatcher.h:46, src/ORBmatcher.cc:1805-1821).  In the reference tree the body of that
-// one function is replaced by the single forwarding line below; Search*/Fuse methods without a forwarding
-// body here keep their CPU bodies and call it as before.  Batched dense matching goes through orbhip_knn2*.
+// one function is replaced by the single forwarding line below; SearchForTriangulation, the one method without a
+// forwarding body here, keeps its CPU body and calls it as before.  Batched dense matching goes through orbhip_knn2*.
 #ifndef ORBMATCHER_ACCEL_H
 #define ORBMATCHER_ACCEL_H
 #ifdef ORBHIP_SHIM_CV_STUB
@@ -373,6 +373,256 @@ struct ORBmatcherAccel {
         for (int i = 0; i < n; i++)
             if (owner[i] >= 0) CurrentFrame.mvpMapPoints[i] = vpMPs[owner[i]];
         return nmatches;
+    }
+
+    // ---- Fuse and SearchBySim3 ------------------------------------------------------------------------
+    // bestIdx / bestDist of every probe among the features of one keyframe ("match to the most similar keypoint
+    // in the radius", src/ORBmatcher.cc:1096-1124): -1 / INT_MAX where the probe is not valid or nothing passes.
+    template <class FrameT, class KeyFrameT>
+    void BestInRadius(KeyFrameT* pKF, const std::vector<OrbProbe>& probes, const std::vector<unsigned char>& pdesc, int nprobes,
+                      std::vector<int>& bestIdx, std::vector<int>& bestDist) {
+        const std::vector<cv::KeyPoint> keys = pKF->GetKeyPointsUn();
+        const std::vector<unsigned char> desc = packRows(pKF->GetDescriptors());
+        const OrbFrameBounds b = {FrameT::mnMinX, FrameT::mnMinY, FrameT::mnMaxX, FrameT::mnMaxY};
+        bestIdx.assign(nprobes ? nprobes : 1, -1);
+        bestDist.assign(nprobes ? nprobes : 1, INT_MAX);
+        if (orbhip_best_in_radius(handle, probes.data(), pdesc.data(), nprobes, (const OrbKeypoint*)keys.data(), desc.data(),
+                                  (int)keys.size(), b, bestIdx.data(), bestDist.data()) != ORBHIP_OK)
+            throw std::runtime_error(orbhip_last_error());
+    }
+
+    // The lines of Fuse from "Depth must be positive" to the radius (src/ORBmatcher.cc:1057-1094, :1185-1223) for one
+    // map point; false where the reference takes a `continue`.
+    template <class KeyFrameT, class MapPointT>
+    static bool FuseProbe(KeyFrameT* pKF, MapPointT* pMP, const cv::Mat& Rcw, const cv::Mat& tcw, const cv::Mat& Ow,
+                          const std::vector<float>& vfScaleFactors, float th, OrbProbe& q) {
+        ClearProbe(q);
+        const float &fx = pKF->fx, &fy = pKF->fy, &cx = pKF->cx, &cy = pKF->cy;
+        const int nMaxLevel = pKF->GetScaleLevels() - 1;
+        cv::Mat p3Dw = pMP->GetWorldPos();
+        cv::Mat p3Dc = Rcw * p3Dw + tcw;
+        if (p3Dc.template at<float>(2) < 0.0f) return false;
+        const float invz = 1 / p3Dc.template at<float>(2);
+        const float x = p3Dc.template at<float>(0) * invz;
+        const float y = p3Dc.template at<float>(1) * invz;
+        const float u = fx * x + cx;
+        const float v = fy * y + cy;
+        if (!pKF->IsInImage(u, v)) return false;
+        const float maxDistance = pMP->GetMaxDistanceInvariance();
+        const float minDistance = pMP->GetMinDistanceInvariance();
+        cv::Mat PO = p3Dw - Ow;
+        const float dist3D = cv::norm(PO);
+        if (dist3D < minDistance || dist3D > maxDistance) return false;
+        cv::Mat Pn = pMP->GetNormal();
+        if (PO.dot(Pn) < 0.5 * dist3D) return false;
+        const float ratio = dist3D / minDistance;
+        std::vector<float>::const_iterator it = std::lower_bound(vfScaleFactors.begin(), vfScaleFactors.end(), ratio);
+        const int nPredictedLevel = std::min(static_cast<int>(it - vfScaleFactors.begin()), nMaxLevel);
+        q.u = u;
+        q.v = v;
+        q.r = th * vfScaleFactors[nPredictedLevel];
+        q.min_level = nPredictedLevel - 1;  // the kpLevel test of :1112-1113 / :1241-1242
+        q.max_level = nPredictedLevel;
+        q.valid = 1;
+        return true;
+    }
+
+    // Both forms of Fuse.  Pass 1 projects every map point and searches all of them in one device call; pass 2 is
+    // the reference's loop with its pointer tests, Replace / AddObservation / AddMapPoint in the reference's order
+    // (they change what later iterations see: GetMapPoint(bestIdx), isBad(), IsInKeyFrame).  A map point that
+    // occurs a second time in the list is searched again at that moment, because a Replace in between may have
+    // given it another descriptor (MapPoint::Replace ends in ComputeDistinctiveDescriptors, src/MapPoint.cc:160).
+    template <class FrameT, class KeyFrameT, class MapPointT, class SkipT, class FuseT>
+    int FuseLoop(KeyFrameT* pKF, const std::vector<MapPointT*>& vpMapPoints, const cv::Mat& Rcw, const cv::Mat& tcw,
+                 const cv::Mat& Ow, float th, SkipT skip, FuseT fuse) {
+        const std::vector<float> vfScaleFactors = pKF->GetScaleFactors();
+        const int nmp = (int)vpMapPoints.size();
+        std::vector<OrbProbe> probes(nmp ? nmp : 1);
+        std::vector<unsigned char> pdesc((size_t)(nmp ? nmp : 1) * 32);
+        for (int i = 0; i < nmp; i++) {
+            ClearProbe(probes[i]);
+            MapPointT* pMP = vpMapPoints[i];
+            if (!pMP) continue;
+            if (FuseProbe(pKF, pMP, Rcw, tcw, Ow, vfScaleFactors, th, probes[i])) CopyDescriptor(pMP->GetDescriptor(), &pdesc[(size_t)i * 32]);
+        }
+        std::vector<int> vBestIdx, vBestDist;
+        BestInRadius<FrameT>(pKF, probes, pdesc, nmp, vBestIdx, vBestDist);
+        std::set<MapPointT*> seen;
+        int nFused = 0;
+        for (int i = 0; i < nmp; i++) {
+            MapPointT* pMP = vpMapPoints[i];
+            if (!pMP) continue;
+            if (skip(pMP)) continue;
+            int bestDist = vBestDist[i];
+            int bestIdx = vBestIdx[i];
+            if (!seen.insert(pMP).second) {
+                std::vector<OrbProbe> one(1);
+                std::vector<unsigned char> d(32);
+                std::vector<int> bi, bd;
+                if (FuseProbe(pKF, pMP, Rcw, tcw, Ow, vfScaleFactors, th, one[0])) CopyDescriptor(pMP->GetDescriptor(), &d[0]);
+                BestInRadius<FrameT>(pKF, one, d, 1, bi, bd);
+                bestIdx = bi[0];
+                bestDist = bd[0];
+            }
+            // If there is already a MapPoint replace otherwise add new measurement
+            if (bestDist <= TH_LOW) {
+                fuse(pMP, bestIdx);
+                nFused++;
+            }
+        }
+        return nFused;
+    }
+
+    // int Fuse(KeyFrame* pKF, std::vector<MapPoint *> &vpMapPoints, float th=2.5)
+    // (include/ORBmatcher.h:87, src/ORBmatcher.cc:1027-1145)
+    template <class FrameT, class KeyFrameT, class MapPointT>
+    int Fuse(KeyFrameT* pKF, std::vector<MapPointT*>& vpMapPoints, float th = 2.5) {
+        cv::Mat Rcw = pKF->GetRotation();
+        cv::Mat tcw = pKF->GetTranslation();
+        cv::Mat Ow = pKF->GetCameraCenter();
+        return FuseLoop<FrameT>(
+            pKF, vpMapPoints, Rcw, tcw, Ow, th, [&](MapPointT* pMP) { return pMP->isBad() || pMP->IsInKeyFrame(pKF); },
+            [&](MapPointT* pMP, int bestIdx) {
+                MapPointT* pMPinKF = pKF->GetMapPoint(bestIdx);
+                if (pMPinKF) {
+                    if (!pMPinKF->isBad()) pMP->Replace(pMPinKF);
+                } else {
+                    pMP->AddObservation(pKF, bestIdx);
+                    pKF->AddMapPoint(pMP, bestIdx);
+                }
+            });
+    }
+
+    // int Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*> &vpPoints, float th=2.5)
+    // (include/ORBmatcher.h:90, src/ORBmatcher.cc:1147-1276)
+    template <class FrameT, class KeyFrameT, class MapPointT>
+    int Fuse(KeyFrameT* pKF, cv::Mat Scw, const std::vector<MapPointT*>& vpPoints, float th = 2.5) {
+        cv::Mat sRcw = Scw.rowRange(0, 3).colRange(0, 3);
+        const float scw = sqrt(sRcw.row(0).dot(sRcw.row(0)));
+        cv::Mat Rcw = sRcw / scw;
+        cv::Mat tcw = Scw.rowRange(0, 3).col(3) / scw;
+        cv::Mat Ow = -Rcw.t() * tcw;
+        std::set<MapPointT*> spAlreadyFound = pKF->GetMapPoints();
+        return FuseLoop<FrameT>(
+            pKF, vpPoints, Rcw, tcw, Ow, th, [&](MapPointT* pMP) { return pMP->isBad() || spAlreadyFound.count(pMP); },
+            [&](MapPointT* pMP, int bestIdx) {
+                MapPointT* pMPinKF = pKF->GetMapPoint(bestIdx);
+                if (pMPinKF) {
+                    if (!pMPinKF->isBad()) pMPinKF->Replace(pMP);
+                } else {
+                    pMP->AddObservation(pKF, bestIdx);
+                    pKF->AddMapPoint(pMP, bestIdx);
+                }
+            });
+    }
+
+    // int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint *> &vpMatches12, const float &s12,
+    //                  const cv::Mat &R12, const cv::Mat &t12, float th)
+    // (include/ORBmatcher.h:84, src/ORBmatcher.cc:1278-1516): the reference's lines up to each GetFeaturesInArea
+    // build the probes of both directions, two device searches, then the reference's agreement check.
+    template <class FrameT, class KeyFrameT, class MapPointT>
+    int SearchBySim3(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<MapPointT*>& vpMatches12, const float& s12,
+                     const cv::Mat& R12, const cv::Mat& t12, float th) {
+        const float fx = pKF1->fx;
+        const float fy = pKF1->fy;
+        const float cx = pKF1->cx;
+        const float cy = pKF1->cy;
+        cv::Mat R1w = pKF1->GetRotation();
+        cv::Mat t1w = pKF1->GetTranslation();
+        cv::Mat R2w = pKF2->GetRotation();
+        cv::Mat t2w = pKF2->GetTranslation();
+        cv::Mat sR12 = s12 * R12;
+        cv::Mat sR21 = (1.0 / s12) * R12.t();
+        cv::Mat t21 = -sR21 * t12;
+        const int nMaxLevel1 = pKF1->GetScaleLevels() - 1;
+        std::vector<float> vfScaleFactors1 = pKF1->GetScaleFactors();
+        std::vector<MapPointT*> vpMapPoints1 = pKF1->GetMapPointMatches();
+        const int N1 = vpMapPoints1.size();
+        const int nMaxLevel2 = pKF2->GetScaleLevels() - 1;
+        std::vector<float> vfScaleFactors2 = pKF2->GetScaleFactors();
+        std::vector<MapPointT*> vpMapPoints2 = pKF2->GetMapPointMatches();
+        const int N2 = vpMapPoints2.size();
+        std::vector<bool> vbAlreadyMatched1(N1, false);
+        std::vector<bool> vbAlreadyMatched2(N2, false);
+        for (int i = 0; i < N1; i++) {
+            MapPointT* pMP = vpMatches12[i];
+            if (pMP) {
+                vbAlreadyMatched1[i] = true;
+                int idx2 = pMP->GetIndexInKeyFrame(pKF2);
+                if (idx2 >= 0 && idx2 < N2) vbAlreadyMatched2[idx2] = true;
+            }
+        }
+        // one direction: the map points of `from` (already in the camera of `from`: Rfw, tfw), moved into the camera
+        // of `to` by sR * p + t and searched among the features of `to`
+        struct Direction {
+            static void Probes(const std::vector<MapPointT*>& vpMapPoints, const std::vector<bool>& vbAlreadyMatched,
+                               const cv::Mat& Rfw, const cv::Mat& tfw, const cv::Mat& sR, const cv::Mat& t, KeyFrameT* pKFto,
+                               const std::vector<float>& vfScaleFactorsTo, int nMaxLevelTo, float fx, float fy, float cx, float cy,
+                               float th, std::vector<OrbProbe>& probes, std::vector<unsigned char>& pdesc) {
+                const int N = (int)vpMapPoints.size();
+                probes.resize(N ? N : 1);
+                pdesc.assign((size_t)(N ? N : 1) * 32, 0);
+                for (int i = 0; i < N; i++) {
+                    OrbProbe& q = probes[i];
+                    ClearProbe(q);
+                    MapPointT* pMP = vpMapPoints[i];
+                    if (!pMP || vbAlreadyMatched[i]) continue;
+                    if (pMP->isBad()) continue;
+                    cv::Mat p3Dw = pMP->GetWorldPos();
+                    cv::Mat p3Dcf = Rfw * p3Dw + tfw;
+                    cv::Mat p3Dct = sR * p3Dcf + t;
+                    if (p3Dct.template at<float>(2) < 0.0) continue;
+                    float invz = 1.0 / p3Dct.template at<float>(2);
+                    float x = p3Dct.template at<float>(0) * invz;
+                    float y = p3Dct.template at<float>(1) * invz;
+                    float u = fx * x + cx;
+                    float v = fy * y + cy;
+                    if (!pKFto->IsInImage(u, v)) continue;
+                    float maxDistance = pMP->GetMaxDistanceInvariance();
+                    float minDistance = pMP->GetMinDistanceInvariance();
+                    float dist3D = cv::norm(p3Dct);
+                    if (dist3D < minDistance || dist3D > maxDistance) continue;
+                    float ratio = dist3D / minDistance;
+                    std::vector<float>::const_iterator it = std::lower_bound(vfScaleFactorsTo.begin(), vfScaleFactorsTo.end(), ratio);
+                    const int nPredictedLevel = std::min(static_cast<int>(it - vfScaleFactorsTo.begin()), nMaxLevelTo);
+                    q.u = u;
+                    q.v = v;
+                    q.r = th * vfScaleFactorsTo[nPredictedLevel];
+                    q.min_level = nPredictedLevel - 1;  // the kp.octave test of :1392-1393 / :1477-1478
+                    q.max_level = nPredictedLevel;
+                    q.valid = 1;
+                    CopyDescriptor(pMP->GetDescriptor(), &pdesc[(size_t)i * 32]);
+                }
+            }
+        };
+        std::vector<OrbProbe> probes1, probes2;
+        std::vector<unsigned char> pdesc1, pdesc2;
+        Direction::Probes(vpMapPoints1, vbAlreadyMatched1, R1w, t1w, sR21, t21, pKF2, vfScaleFactors2, nMaxLevel2, fx, fy, cx, cy, th,
+                          probes1, pdesc1);
+        Direction::Probes(vpMapPoints2, vbAlreadyMatched2, R2w, t2w, sR12, t12, pKF1, vfScaleFactors1, nMaxLevel1, fx, fy, cx, cy, th,
+                          probes2, pdesc2);
+        std::vector<int> bestIdx1, bestDist1, bestIdx2, bestDist2;
+        BestInRadius<FrameT>(pKF2, probes1, pdesc1, N1, bestIdx1, bestDist1);
+        BestInRadius<FrameT>(pKF1, probes2, pdesc2, N2, bestIdx2, bestDist2);
+        std::vector<int> vnMatch1(N1, -1);
+        std::vector<int> vnMatch2(N2, -1);
+        for (int i1 = 0; i1 < N1; i1++)
+            if (bestDist1[i1] <= TH_HIGH) vnMatch1[i1] = bestIdx1[i1];
+        for (int i2 = 0; i2 < N2; i2++)
+            if (bestDist2[i2] <= TH_HIGH) vnMatch2[i2] = bestIdx2[i2];
+        // Check agreement
+        int nFound = 0;
+        for (int i1 = 0; i1 < N1; i1++) {
+            int idx2 = vnMatch1[i1];
+            if (idx2 >= 0) {
+                int idx1 = vnMatch2[idx2];
+                if (idx1 == i1) {
+                    vpMatches12[i1] = vpMapPoints2[idx2];
+                    nFound++;
+                }
+            }
+        }
+        return nFound;
     }
 
     // ---- SearchByBoW --------------------------------------------------------------------------------

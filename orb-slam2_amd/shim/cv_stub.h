@@ -104,10 +104,31 @@ struct MatMul_ {
     bool ta;
     double alpha;
 };
+struct MatScaled_ {  // -A: a matrix with a scale that a following product folds into its alpha
+    Mat a;
+    double alpha;
+};
 inline MatT_ Mat::t() const { return MatT_{*this, 1.0}; }
 inline MatT_ operator-(const MatT_& t) { return MatT_{t.a, -t.alpha}; }
+inline MatScaled_ operator-(const Mat& a) { return MatScaled_{a, -1.0}; }
 inline MatMul_ operator*(const Mat& a, const Mat& b) { return MatMul_{a, b, false, 1.0}; }
 inline MatMul_ operator*(const MatT_& a, const Mat& b) { return MatMul_{a.a, b, true, a.alpha}; }
+inline MatMul_ operator*(const MatScaled_& a, const Mat& b) { return MatMul_{a.a, b, false, a.alpha}; }
+// s * M and s * M.t(): convertTo with scale s (after the transpose), i.e. a float multiply by (float)s
+inline Mat operator*(double s, const Mat& a) {
+    const float f = (float)s;
+    Mat o(a.rows, a.cols, CV_32F);
+    for (int i = 0; i < a.rows; i++)
+        for (int j = 0; j < a.cols; j++) o.at<float>(i, j) = a.at<float>(i, j) * f;
+    return o;
+}
+inline Mat operator*(double s, const MatT_& t) {
+    const float f = (float)(s * t.alpha);
+    Mat o(t.a.cols, t.a.rows, CV_32F);
+    for (int i = 0; i < t.a.cols; i++)
+        for (int j = 0; j < t.a.rows; j++) o.at<float>(i, j) = t.a.at<float>(j, i) * f;
+    return o;
+}
 
 // cv::gemm as OpenCV 2.4 evaluates the two shapes the matchers use (CV_32F): a plain product of small
 // matrices accumulates each element in float, left to right, and finishes as (float)(acc*alpha + c*beta) with

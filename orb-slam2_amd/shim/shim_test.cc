@@ -48,8 +48,17 @@ struct FeatureVector : std::map<unsigned int, std::vector<unsigned int> > {
 };
 }  // namespace DBoW2
 
+struct FakeKeyFrame;
 struct FakeMapPoint {
     bool bad;
+    std::map<FakeKeyFrame*, size_t> mObservations;
+    bool IsInKeyFrame(FakeKeyFrame* pKF) { return mObservations.count(pKF) != 0; }
+    int GetIndexInKeyFrame(FakeKeyFrame* pKF) { return mObservations.count(pKF) ? (int)mObservations[pKF] : -1; }
+    void AddObservation(FakeKeyFrame* pKF, size_t idx) {  // src/MapPoint.cc:72-85 without the counters
+        if (mObservations.count(pKF)) return;
+        mObservations[pKF] = idx;
+    }
+    inline void Replace(FakeMapPoint* pMP);  // src/MapPoint.cc:130-164 without the descriptor update and the map
     // tracking fields written by Frame::isInFrustum (include/MapPoint.h)
     bool mbTrackInView;
     int mnTrackScaleLevel;
@@ -98,7 +107,42 @@ struct FakeKeyFrame {
     cv::Mat GetDescriptors() { return descriptors.clone(); }
     std::vector<FakeMapPoint*> GetMapPointMatches() { return mapPoints; }
     DBoW2::FeatureVector GetFeatureVector() { return featVec; }
+    // pose, as KeyFrame::SetPose keeps it (src/KeyFrame.cc:102-109)
+    cv::Mat Rcw, tcw, Ow;
+    void SetPose(const cv::Mat& Tcw) {
+        Rcw = Tcw.rowRange(0, 3).colRange(0, 3).clone();
+        tcw = Tcw.rowRange(0, 3).col(3).clone();
+        Ow = -Rcw.t() * tcw;
+    }
+    cv::Mat GetRotation() { return Rcw.clone(); }
+    cv::Mat GetTranslation() { return tcw.clone(); }
+    cv::Mat GetCameraCenter() { return Ow.clone(); }
+    FakeMapPoint* GetMapPoint(const size_t& idx) { return mapPoints[idx]; }
+    void AddMapPoint(FakeMapPoint* pMP, const size_t& idx) { mapPoints[idx] = pMP; }
+    void ReplaceMapPointMatch(const size_t& idx, FakeMapPoint* pMP) { mapPoints[idx] = pMP; }
+    void EraseMapPointMatch(const size_t& idx) { mapPoints[idx] = 0; }
+    std::set<FakeMapPoint*> GetMapPoints() {
+        std::set<FakeMapPoint*> s;
+        for (size_t i = 0; i < mapPoints.size(); i++)
+            if (mapPoints[i]) s.insert(mapPoints[i]);
+        return s;
+    }
 };
+inline void FakeMapPoint::Replace(FakeMapPoint* pMP) {
+    if (pMP == this) return;
+    std::map<FakeKeyFrame*, size_t> obs = mObservations;
+    mObservations.clear();
+    bad = true;
+    for (std::map<FakeKeyFrame*, size_t>::iterator mit = obs.begin(), mend = obs.end(); mit != mend; mit++) {
+        FakeKeyFrame* pKF = mit->first;
+        if (!pMP->IsInKeyFrame(pKF)) {
+            pKF->ReplaceMapPointMatch(mit->second, pMP);
+            pMP->AddObservation(pKF, mit->second);
+        } else {
+            pKF->EraseMapPointMatch(mit->second);
+        }
+    }
+}
 
 // shim_test --latency <in.raw> <rows> <cols> <nfeatures> <calls>: the call of src/Frame.cc:61 repeated on one
 // image, one frame per call as the tracking thread makes it; prints the median, 10th and 90th percentile of the
@@ -275,6 +319,116 @@ static int matchers_mode(int argc, char** argv) {
         }
         write_blob(out, &nmatches, 4);
         write_blob(out, owner.data(), sizeof(int) * n);
+    } else if (mode == "fuse_pose" || mode == "fuse_sim3") {
+        // blobs 0-13 as above (1: {fx, fy, cx, cy, unused, th}; 6: Tcw or Scw; 8: 0 usable, 1 NULL, 2 bad, 3 already in
+        // the keyframe), 14: per point the feature that holds it on entry (kind 3) or -1.  A taken feature holds a
+        // map point of its own.  Map point ids in the output: candidate i = i, the point held by feature j = npts + j.
+        const float* fp = as<float>(in[1]);
+        const int* bd = as<int>(in[2]);
+        FakeFrame::mnMinX = bd[0]; FakeFrame::mnMinY = bd[1]; FakeFrame::mnMaxX = bd[2]; FakeFrame::mnMaxY = bd[3];
+        ORB_SLAM::ORBmatcherAccel matcher;
+        FakeKeyFrame KF;
+        KF.fx = fp[0]; KF.fy = fp[1]; KF.cx = fp[2]; KF.cy = fp[3];
+        KF.keysUn = keypoints(in[3]);
+        KF.descriptors = mat_desc(in[4]);
+        const int nlev = (int)(in[7].size() / 4);
+        KF.scaleFactors.assign(as<float>(in[7]), as<float>(in[7]) + nlev);
+        const int n = (int)KF.keysUn.size(), npts = (int)in[8].size();
+        std::vector<FakeMapPoint> pts(npts + n);
+        KF.mapPoints.assign(n, (FakeMapPoint*)0);
+        for (int j = 0; j < n; j++)
+            if (in[5][j]) {
+                KF.mapPoints[j] = &pts[npts + j];
+                pts[npts + j].mObservations[&KF] = j;
+            }
+        cv::Mat pdesc = mat_desc(in[13]);
+        std::vector<FakeMapPoint*> vp(npts);
+        for (int i = 0; i < npts; i++) {
+            pts[i].bad = in[8][i] == 2;
+            pts[i].pos = mat_f32(3, 1, as<float>(in[9]) + 3 * i);
+            pts[i].normal = mat_f32(3, 1, as<float>(in[10]) + 3 * i);
+            pts[i].minDist = as<float>(in[11])[i];
+            pts[i].maxDist = as<float>(in[12])[i];
+            pts[i].descriptor = pdesc.row(i);
+            vp[i] = in[8][i] == 1 ? (FakeMapPoint*)0 : &pts[i];
+            const int host = as<int>(in[14])[i];
+            if (in[8][i] == 3 && host >= 0) {
+                pts[npts + host].mObservations.clear();
+                KF.mapPoints[host] = &pts[i];
+                pts[i].mObservations[&KF] = host;
+            }
+        }
+        cv::Mat T = mat_f32(4, 4, as<float>(in[6]));
+        int nFused;
+        if (mode == "fuse_pose") {
+            KF.SetPose(T);
+            nFused = matcher.Fuse<FakeFrame>(&KF, vp, fp[5]);
+        } else {
+            nFused = matcher.Fuse<FakeFrame>(&KF, T, (const std::vector<FakeMapPoint*>&)vp, fp[5]);
+        }
+        std::vector<int> slot(n ? n : 1, -1), isbad(npts + n ? npts + n : 1, 0), obs(npts + n ? npts + n : 1, -1);
+        for (int j = 0; j < n; j++)
+            if (KF.mapPoints[j]) slot[j] = (int)(KF.mapPoints[j] - &pts[0]);
+        for (int i = 0; i < npts + n; i++) {
+            isbad[i] = pts[i].bad;
+            obs[i] = pts[i].GetIndexInKeyFrame(&KF);
+        }
+        write_blob(out, &nFused, 4);
+        write_blob(out, slot.data(), sizeof(int) * n);
+        write_blob(out, isbad.data(), sizeof(int) * (npts + n));
+        write_blob(out, obs.data(), sizeof(int) * (npts + n));
+    } else if (mode == "sim3search") {
+        // blobs: 0 float {fx, fy, cx, cy, s12, th}, 1 bounds, 2 scale factors, 3 T1w, 4 T2w, 5 R12, 6 t12, then per keyframe
+        // (7.., 15..): keypoints, descriptors, kind per keypoint's map point (0 usable, 1 NULL, 2 bad, 3 (keyframe 1 only)
+        // matched on entry), positions, min distance, max distance, point descriptors, partner (keyframe 1, kind 3: the
+        // feature of keyframe 2 its match on entry is observed at, or -1)
+        const float* fp = as<float>(in[0]);
+        const int* bd = as<int>(in[1]);
+        FakeFrame::mnMinX = bd[0]; FakeFrame::mnMinY = bd[1]; FakeFrame::mnMaxX = bd[2]; FakeFrame::mnMaxY = bd[3];
+        ORB_SLAM::ORBmatcherAccel matcher;
+        FakeKeyFrame KF[2];
+        std::vector<FakeMapPoint> pts[2];
+        const int nlev = (int)(in[2].size() / 4);
+        for (int s = 0; s < 2; s++) {
+            const int o = 7 + 8 * s;
+            KF[s].fx = fp[0]; KF[s].fy = fp[1]; KF[s].cx = fp[2]; KF[s].cy = fp[3];
+            KF[s].keysUn = keypoints(in[o]);
+            KF[s].descriptors = mat_desc(in[o + 1]);
+            KF[s].scaleFactors.assign(as<float>(in[2]), as<float>(in[2]) + nlev);
+            KF[s].SetPose(mat_f32(4, 4, as<float>(in[3 + s])));
+            const int n = (int)KF[s].keysUn.size();
+            pts[s].resize(n);
+            KF[s].mapPoints.assign(n, (FakeMapPoint*)0);
+            cv::Mat pdesc = mat_desc(in[o + 6]);
+            for (int i = 0; i < n; i++) {
+                pts[s][i].bad = in[o + 2][i] == 2;
+                pts[s][i].pos = mat_f32(3, 1, as<float>(in[o + 3]) + 3 * i);
+                pts[s][i].minDist = as<float>(in[o + 4])[i];
+                pts[s][i].maxDist = as<float>(in[o + 5])[i];
+                pts[s][i].descriptor = pdesc.row(i);
+                if (in[o + 2][i] != 1) KF[s].mapPoints[i] = &pts[s][i];
+            }
+        }
+        const int n1 = (int)pts[0].size();
+        std::vector<FakeMapPoint> prior(n1 ? n1 : 1);  // the matches vpMatches12 holds on entry
+        std::vector<FakeMapPoint*> vpMatches12(n1, (FakeMapPoint*)0);
+        for (int i = 0; i < n1; i++)
+            if (in[9][i] == 3) {
+                vpMatches12[i] = &prior[i];
+                const int partner = as<int>(in[14])[i];
+                if (partner >= 0) prior[i].mObservations[&KF[1]] = partner;
+            }
+        cv::Mat R12 = mat_f32(3, 3, as<float>(in[5])), t12 = mat_f32(3, 1, as<float>(in[6]));
+        const float s12 = fp[4];
+        const int nFound = matcher.SearchBySim3<FakeFrame>(&KF[0], &KF[1], vpMatches12, s12, R12, t12, fp[5]);
+        std::vector<int> idx(n1 ? n1 : 1, -1);
+        for (int i = 0; i < n1; i++) {
+            FakeMapPoint* q = vpMatches12[i];
+            if (!q) continue;
+            idx[i] = (!pts[1].empty() && q >= &pts[1][0] && q < &pts[1][0] + pts[1].size()) ? (int)(q - &pts[1][0]) : -3;
+        }
+        write_blob(out, &nFound, 4);
+        write_blob(out, idx.data(), sizeof(int) * n1);
     } else if (mode == "bow_kf_f" || mode == "bow_kf_kf") {
         // blobs: 0 float {ratio}, 1 int {check_ori}, then per side (2.., 8..): keypoints, descriptors, valid, fv nodes,
         // fv start, fv features

@@ -189,3 +189,136 @@ def test_distinctive_undistort_computebow_through_the_cpp_bodies(orb, orbref, sy
     assert np.array_equal(np.frombuffer(out[3], np.int32), rs)
     assert np.array_equal(np.frombuffer(out[4], np.int32), rf)
     assert len(rw) > 300
+
+
+def simulate_fuse(n_feat, npts, taken, kinds, host, best_idx, best_dist, sim3):
+    """What the loop of ORBmatcher::Fuse leaves behind (src/ORBmatcher.cc:1044-1142, :1171-1272; MapPoint::Replace,
+    src/MapPoint.cc:130-164) given bestIdx / bestDist per map point.  Map point ids as the test program numbers them:
+    candidate i = i, the point a taken feature j holds on entry = npts + j."""
+    slot = np.full(n_feat, -1, np.int64)
+    bad = np.zeros(npts + n_feat, bool)
+    obs = np.full(npts + n_feat, -1, np.int64)
+    for j in np.nonzero(taken)[0]:
+        slot[j] = npts + j
+        obs[npts + j] = j
+    bad[:npts] = kinds == 2
+    for i in np.nonzero(kinds == 3)[0]:
+        if host[i] >= 0:
+            obs[slot[host[i]]] = -1
+            slot[host[i]] = i
+            obs[i] = host[i]
+    found_on_entry = set(int(x) for x in slot[slot >= 0])
+
+    def replace(this, other):  # this->Replace(other)
+        if this == other:
+            return
+        at = obs[this]
+        obs[this] = -1
+        bad[this] = True
+        if at >= 0:
+            if obs[other] < 0:
+                slot[at] = other
+                obs[other] = at
+            else:
+                slot[at] = -1
+
+    fused = 0
+    for i in range(npts):
+        if kinds[i] == 1 or bad[i]:
+            continue
+        if (i in found_on_entry) if sim3 else obs[i] >= 0:
+            continue
+        if best_dist[i] <= 20:
+            j = best_idx[i]
+            held = slot[j]
+            if held >= 0:
+                if not bad[held]:
+                    if sim3:
+                        replace(held, i)
+                    else:
+                        replace(i, held)
+            else:
+                if obs[i] < 0:
+                    obs[i] = j
+                slot[j] = i
+            fused += 1
+    return fused, slot, bad, obs
+
+
+@pytest.mark.parametrize("sim3", [False, True])
+@pytest.mark.parametrize("n", [1300, 0, 1])
+def test_fuse_through_the_cpp_bodies(orb, orbref, tmp_path, n, sim3):
+    """Both forms of ORBmatcher::Fuse (src/ORBmatcher.cc:1027-1145, :1147-1276): pose arithmetic on cv::Mat, the
+    device search, and the Replace / AddObservation / AddMapPoint sequence on stand-in map points."""
+    from test_gpu_fuse import map_point_geometry
+    rng = np.random.default_rng(600 + n + sim3)
+    scale = 1.3 if sim3 else 1.0
+    T = pose(rng, scale=scale)
+    s = Scene(orbref, rng, n, 640, 480, T, ties=True)
+    normal, min_d, max_d = map_point_geometry(rng, s, T, scale)
+    nf = len(s.kp)
+    kinds = kinds_for(rng, n, int(s.taken.sum()), with_null=not sim3)
+    host = np.full(n, -1, np.int32)
+    free = list(np.nonzero(s.taken)[0])
+    for i in np.nonzero(kinds == 3)[0]:
+        host[i] = free.pop()
+    skip = (kinds != 0).astype(np.uint8)
+    rn, bi, bd, _ = orbref.fuse(s.kp, s.desc, s.bounds, s.K, SCALE, T, skip, s.pos, normal, min_d, max_d, s.mp_desc, 3.0, sim3=sim3)
+    blobs = [np.zeros(4, np.int32), np.array(list(s.K) + [0.0, 3.0], np.float32), np.array(s.bounds, np.int32), s.kp, s.desc, s.taken,
+             np.asarray(T, np.float32), SCALE, kinds, s.pos, normal, min_d, max_d, s.mp_desc, host]
+    out = run(tmp_path, "fuse_sim3" if sim3 else "fuse_pose", blobs)
+    fused = int(np.frombuffer(out[0], np.int32)[0])
+    slot, isbad, obs = (np.frombuffer(out[k], np.int32) for k in (1, 2, 3))
+    e_fused, e_slot, e_bad, e_obs = simulate_fuse(nf, n, s.taken, kinds, host, bi, bd, sim3)
+    assert fused == e_fused == rn
+    assert np.array_equal(slot, e_slot) and np.array_equal(isbad != 0, e_bad) and np.array_equal(obs, e_obs)
+    if n >= 1000:
+        replaced = int(e_bad.sum() - (kinds == 2).sum())
+        assert fused > 250 and replaced > 20 and (e_slot[s.taken == 0] >= 0).sum() > 100
+
+
+@pytest.mark.parametrize("n", [1600, 0, 1])
+def test_search_by_sim3_through_the_cpp_body(orb, orbref, tmp_path, n):
+    """ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:1278-1516): the Sim3 algebra on cv::Mat, both device searches and the
+    agreement check."""
+    from test_gpu_fuse import two_views
+    rng = np.random.default_rng(700 + n)
+    w, h, s12, th = 752, 480, np.float32(0.93), 7.5
+    T1, T2 = pose(rng), pose(rng)
+    K, (v1, v2), T2s, R12, t12, mp_desc, level = two_views(orbref, rng, n, w, h, T1, T2, float(s12))
+    bounds = [0, 0, w, h]
+    side, kinds = [], []
+    for v, other, with3 in ((v1, v2, True), (v2, v1, False)):
+        k = len(v["kp"])
+        has = v["owner"] >= 0
+        o = np.where(has, v["owner"], 0)
+        kd = rng.choice(np.array([0, 2, 3 if with3 else 0], np.uint8), k, p=[0.88, 0.06, 0.06])
+        kd[~has] = 1
+        pos = np.where(has[:, None], v["pos"][o] if n else np.zeros((k, 3), np.float32), 0).astype(np.float32)
+        d_other = other["dist"][o] if n else np.zeros(k)
+        min_d = (d_other / SCALE[level[o] if n else np.zeros(k, int)] * rng.uniform(0.85, 1.18, k)).astype(np.float32)
+        max_d = (min_d * 1.2 ** 7.5).astype(np.float32)
+        d = np.where(has[:, None], mp_desc[o] if n else np.zeros((k, 32), np.uint8), 0).astype(np.uint8)
+        side.append([None, pos, min_d, max_d, d])
+        kinds.append(kd)
+    n1, n2 = len(v1["kp"]), len(v2["kp"])
+    partner = np.full(n1, -1, np.int32)
+    matched2 = np.zeros(n2, bool)
+    for i in np.nonzero(kinds[0] == 3)[0]:
+        if n2 and rng.random() < 0.8:
+            partner[i] = rng.integers(0, n2)
+            matched2[partner[i]] = True
+    side[0][0] = (kinds[0] != 0).astype(np.uint8)
+    side[1][0] = ((kinds[1] != 0) | matched2).astype(np.uint8)
+    nfound, m12, _, _, _, _ = orbref.search_by_sim3(v1["kp"], v1["desc"], v2["kp"], v2["desc"], bounds, K, SCALE, T1, T2s, s12, R12,
+                                                    t12, th, *side[0], *side[1])
+    blobs = [np.array(list(K) + [s12, th], np.float32), np.array(bounds, np.int32), SCALE, np.asarray(T1, np.float32),
+             np.asarray(T2s, np.float32), R12, t12]
+    for v, sd, kd, extra in ((v1, side[0], kinds[0], partner), (v2, side[1], kinds[1], np.zeros(0, np.int32))):
+        blobs += [v["kp"], v["desc"], kd, sd[1], sd[2], sd[3], sd[4], extra]
+    out = run(tmp_path, "sim3search", blobs)
+    got_n, got = int(np.frombuffer(out[0], np.int32)[0]), np.frombuffer(out[1], np.int32)
+    assert got_n == nfound
+    assert np.array_equal(got, np.where(kinds[0] == 3, -3, m12))
+    if n >= 1000:
+        assert nfound > 200

@@ -288,6 +288,86 @@ def test_projection_sim3_and_keyframe_by_hand(orbref):
     assert n == 0
 
 
+def test_fuse_by_hand(orbref):
+    """The geometry of the Sim3 projection test above (camera at (0, 0, -0.5), point (0.5, 0, 1.5) -> (75, 50), levels
+    1..2, radius th * 1.44).  Fuse has no "already matched" skip: two equal map points find the same feature, and the
+    first of two equally distant features (GetFeaturesInArea order) wins."""
+    sf = np.array([1.0, 1.2, 1.44], np.float32)
+    T = np.eye(4, dtype=np.float32)
+    T[2, 3] = 0.5
+    S = np.eye(4, dtype=np.float32) * 2
+    S[3, 3] = 1
+    S[2, 3] = 1.0
+    pos = np.array([[0.5, 0, 1.5], [0.5, 0, 1.5]], np.float32)
+    dist = np.float32(np.sqrt(4.25))
+    min_d = np.array([dist / np.float32(1.3)] * 2, np.float32)
+    max_d = min_d * 10
+    normal = np.array([[0, 0, 1], [0, 0, 1]], np.float32)
+    K = (100.0, 100.0, 50.0, 50.0)
+    kf = kps(orbref, [(75, 50, 0), (80, 55, 1), (76, 50, 2), (70, 45, 2)])
+    dkf = np.stack([bits(0), bits(20), bits(21), bits(20)])
+    mp = np.stack([bits(0), bits(0)])
+    for T_, sim3 in ((T, False), (S, True)):
+        n, bi, bd, probes = orbref.fuse(kf, dkf, B640, K, sf, T_, [0, 0], pos, normal, min_d, max_d, mp, 2.5, sim3=sim3)
+        assert (probes["u"][0], probes["v"][0], probes["min_level"][0], probes["max_level"][0]) == (75.0, 50.0, 1, 2)
+        assert probes["r"][0] == np.float32(2.5) * sf[2]
+        # radius 3.6 around (75, 50): features 0 (level 0, filtered) and 2 (1 px away, 21 bits) are inside
+        assert n == 0 and list(bi) == [2, 2] and list(bd) == [21, 21]
+        n, bi, bd, _ = orbref.fuse(kf, dkf, B640, K, sf, T_, [0, 0], pos, normal, min_d, max_d, mp, 5.0, sim3=sim3)
+        # radius 7.2: features 1 (20 bits, cell column of x = 80) and 3 (20 bits, column of x = 70) tie; the area is
+        # walked by grid column, so feature 3 comes first
+        assert n == 2 and list(bi) == [3, 3] and list(bd) == [20, 20]
+        n, bi, bd, probes = orbref.fuse(kf, dkf, B640, K, sf, T_, [1, 0], pos, np.array([[0, 0, 1], [1, 0, 0]], np.float32), min_d,
+                                        max_d, mp, 5.0, sim3=sim3)
+        assert n == 0 and list(bi) == [-1, -1] and list(bd) == [INT_MAX, INT_MAX] and list(probes["valid"]) == [0, 0]
+    # a keyframe whose only feature in the radius fails the level test: the scan runs and finds nothing
+    n, bi, bd, probes = orbref.fuse(kf[:1], dkf[:1], B640, K, sf, T, [0], pos[:1], normal[:1], min_d[:1], max_d[:1], mp[:1], 2.5)
+    assert n == 0 and probes["valid"][0] == 1 and bi[0] == -1 and bd[0] == INT_MAX
+
+
+def test_search_by_sim3_by_hand(orbref):
+    """Both cameras at the origin looking down z, identity Sim3 (s12 = 1, R12 = I, t12 = 0): a map point of one
+    keyframe projects to the same pixel in the other.  Point A (0.5, 0, 2) -> (75, 50); point B (1, 0, 2) -> (100, 50).
+    Keyframe 1 holds A at feature 0 and B at feature 1; keyframe 2 holds A at feature 1 and nothing else.  A agrees in
+    both directions; B finds keyframe 2's feature 0 (30 bits <= TH_HIGH) but that feature has no map point to answer."""
+    sf = np.array([1.0, 1.2, 1.44], np.float32)
+    I4 = np.eye(4, dtype=np.float32)
+    K = (100.0, 100.0, 50.0, 50.0)
+    A, B = [0.5, 0, 2], [1, 0, 2]
+    dA = np.float32(np.sqrt(4.25))
+    dB = np.float32(np.sqrt(5.0))
+    kf1 = kps(orbref, [(75, 50, 1), (100, 50, 1)])
+    kf2 = kps(orbref, [(101, 50, 1), (76, 51, 1)])
+    d1 = np.stack([bits(3), bits(0)])
+    d2 = np.stack([bits(30), bits(5)])
+    pos1 = np.array([A, B], np.float32)
+    pos2 = np.array([[0, 0, 0], A], np.float32)
+    min1 = np.array([dA / np.float32(1.1), dB / np.float32(1.1)], np.float32)  # ratio 1.1 -> level 1, levels 0..1
+    min2 = np.array([1, dA / np.float32(1.1)], np.float32)
+    mp1 = np.stack([bits(4), bits(0)])
+    mp2 = np.stack([bits(0), bits(4)])
+    args = (kf1, d1, kf2, d2, B640, K, sf, I4, I4, 1.0, np.eye(3, dtype=np.float32), np.zeros(3, np.float32), 7.5)
+    n, m12, vn1, vn2, pr1, pr2 = orbref.search_by_sim3(*args, [0, 0], pos1, min1, min1 * 10, mp1, [1, 0], pos2, min2, min2 * 10, mp2)
+    assert (pr1["u"][0], pr1["v"][0], pr1["u"][1], pr2["u"][1]) == (75.0, 50.0, 100.0, 75.0)
+    assert pr1["r"][0] == np.float32(7.5) * sf[1] and (pr1["min_level"][0], pr1["max_level"][0]) == (0, 1)
+    assert list(vn1) == [1, 0] and list(vn2) == [-1, 0]  # A -> feature 1 of keyframe 2 (1 bit), B -> feature 0 (30 bits)
+    assert n == 1 and list(m12) == [1, -1]
+    # beyond TH_HIGH nothing is recorded: B's descriptor against 30 + 101 bits
+    d2b = d2.copy()
+    d2b[0] = bits(131)
+    n, m12, vn1, _, _, _ = orbref.search_by_sim3(kf1, d1, kf2, d2b, *args[4:], [0, 0], pos1, min1, min1 * 10, mp1, [1, 0], pos2, min2,
+                                                 min2 * 10, mp2)
+    assert list(vn1) == [1, -1] and n == 1
+    # a scale: s12 = 2 maps keyframe 2's point (0.25, 0, 1) to (0.5, 0, 2) in camera 1 and camera 1's A to (0.25, 0, 1):
+    # the same pixels, but the distances used for the level prediction halve in keyframe 2
+    pos2s = np.array([[0, 0, 0], [0.25, 0, 1]], np.float32)
+    n, m12, vn1, vn2, pr1, pr2 = orbref.search_by_sim3(kf1, d1, kf2, d2, B640, K, sf, I4, I4, 2.0, np.eye(3, dtype=np.float32),
+                                                       np.zeros(3, np.float32), 7.5, [0, 1], pos1, min1 / 2, min1 * 10, mp1, [1, 0],
+                                                       pos2s, min2, min2 * 10, mp2)
+    assert (pr1["u"][0], pr1["v"][0], pr2["u"][1], pr2["v"][1]) == (75.0, 50.0, 75.0, 50.0)
+    assert n == 1 and list(m12) == [1, -1]
+
+
 def test_projection_frame_to_frame_by_hand(orbref):
     """SearchByProjection(F1, F2, windowSize, ...) (src/ORBmatcher.cc:530-605): same-level window, ratio with <=."""
     T = np.eye(4, dtype=np.float32)
