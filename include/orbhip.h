@@ -452,6 +452,33 @@ int orbhip_search_by_bow_device(orbhip_matcher* m, const OrbKeypoint* d_kp1, con
                                 int check_orientation, int th_low_inclusive, int32_t* d_matches12, int32_t* d_matches21,
                                 int32_t* d_nmatches);
 
+/* Replaces ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:863-1025) for `batch` independent keyframe
+ * pairs: features of keyframe 1 and keyframe 2 that hold no map point (d_free1 / d_free2 non-zero, cap bytes per
+ * frame) and lie under the same vocabulary node are paired — candidates at most TH_LOW away, ordered by (distance,
+ * index), the first within twice the least distance that passes ORBmatcher::CheckDistEpipolarLine (:139-156) —
+ * a feature of keyframe 2 at most once, then the rotation-histogram filter.  d_F12: the fundamental matrix of each
+ * pair (9 floats, row-major, as LocalMapping::ComputeF12 returns it); d_level_sigma2: KeyFrame::GetSigma2(level) for
+ * level < nlevels, shared by all pairs (octaves outside are clamped).  FeatureVectors in the layout of
+ * orbhip_feature_vector_device.  Outputs: d_matches12 (batch*cap) = vMatches12 (the vMatchedPairs of :1014-1022 are
+ * its entries >= 0 in index order), d_matches21 (batch*cap, the inverse), d_nmatches (batch) = the return value.
+ * Device pointers; asynchronous. */
+int orbhip_search_for_triangulation_device(orbhip_matcher* m, const OrbKeypoint* d_kp1, const uint8_t* d_desc1,
+                                           const int32_t* d_n1, const uint8_t* d_free1, const int32_t* d_fv1_nodes,
+                                           const int32_t* d_fv1_start, const int32_t* d_fv1_feat, const int32_t* d_fv1_count,
+                                           const OrbKeypoint* d_kp2, const uint8_t* d_desc2, const int32_t* d_n2,
+                                           const uint8_t* d_free2, const int32_t* d_fv2_nodes, const int32_t* d_fv2_start,
+                                           const int32_t* d_fv2_feat, const int32_t* d_fv2_count, int batch, int cap, int node_cap,
+                                           const float* d_F12, const float* d_level_sigma2, int nlevels, int check_orientation,
+                                           int32_t* d_matches12, int32_t* d_matches21, int32_t* d_nmatches);
+/* Host-pointer form for ONE pair (copy in, match, copy out; blocking): what a forwarding
+ * ORBmatcher::SearchForTriangulation calls.  An octave of keyframe 2 outside [0, nlevels) is ORBHIP_EINVAL. */
+int orbhip_search_for_triangulation(orbhip_matcher* m, const OrbKeypoint* kp1, const uint8_t* desc1, int n1, const uint8_t* free1,
+                                    const int32_t* fv1_nodes, const int32_t* fv1_start, const int32_t* fv1_feat, int fv1_count,
+                                    const OrbKeypoint* kp2, const uint8_t* desc2, int n2, const uint8_t* free2,
+                                    const int32_t* fv2_nodes, const int32_t* fv2_start, const int32_t* fv2_feat, int fv2_count,
+                                    const float* F12, const float* level_sigma2, int nlevels, int check_orientation,
+                                    int32_t* matches12, int32_t* nmatches);
+
 /* Host-pointer form of orbhip_search_by_bow_device for ONE pair (copy in, match, copy out; blocking): what a
  * forwarding ORBmatcher::SearchByBoW (src/ORBmatcher.cc:158-295 with th_low_inclusive = 1 and valid2 = NULL,
  * :726-861 with th_low_inclusive = 0) calls.  A DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned>>,

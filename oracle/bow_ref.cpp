@@ -18,9 +18,11 @@
 //   ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, ...)   src/ORBmatcher.cc:726-861
 #include "orb_ref.h"
 
+#include <algorithm>
 #include <climits>
 #include <cmath>
 #include <map>
+#include <utility>
 #include <vector>
 
 namespace {
@@ -402,6 +404,102 @@ int orbref_search_by_bow_kf_kf(const void* kp1_, const uint8_t* desc1, int n1, c
             }
         }
     }
+    return nmatches;
+}
+
+// ORBmatcher::CheckDistEpipolarLine, src/ORBmatcher.cc:139-156.  F12: 3x3 row-major (CV_32F); sigma2 =
+// pKF2->GetSigma2(kp2.octave), a float (include/KeyFrame.h).
+static bool CheckDistEpipolarLine(const KpB& kp1, const KpB& kp2, const float* F12, const float* mvLevelSigma2) {
+    const float a = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+    const float b = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+    const float c = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+    const float num = a * kp2.x + b * kp2.y + c;
+    const float den = a * a + b * b;
+    if (den == 0) return false;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * mvLevelSigma2[kp2.octave];
+}
+
+// ORBmatcher::SearchForTriangulation, src/ORBmatcher.cc:863-1025.  free1 / free2: the keyframe's feature holds no map
+// point (pMP1 / pMP2 is NULL).  matches12[idx1] = vMatches12 after the orientation filter; vMatchedPairs are its
+// entries >= 0 in index order (:1014-1022).  Returns nmatches.
+int orbref_search_for_triangulation(const void* kp1_, const uint8_t* desc1, int n1, const uint8_t* free1,
+                                    const int32_t* fv1_nodes, const int32_t* fv1_start, const int32_t* fv1_feat, int fv1_n,
+                                    const void* kp2_, const uint8_t* desc2, int n2, const uint8_t* free2,
+                                    const int32_t* fv2_nodes, const int32_t* fv2_start, const int32_t* fv2_feat, int fv2_n,
+                                    const float* F12, const float* mvLevelSigma2, int mbCheckOrientation, int32_t* matches12) {
+    const KpB* vKeysUn1 = (const KpB*)kp1_;
+    const KpB* vKeysUn2 = (const KpB*)kp2_;
+    FeatureVector vFeatVec1 = fv_from_csr(fv1_nodes, fv1_start, fv1_feat, fv1_n);
+    FeatureVector vFeatVec2 = fv_from_csr(fv2_nodes, fv2_start, fv2_feat, fv2_n);
+    int nmatches = 0;
+    std::vector<bool> vbMatched2(n2, false);
+    std::vector<int> vMatches12(n1, -1);
+    std::vector<int> rotHist[BOW_HISTO_LENGTH];
+    const float factor = 1.0f / BOW_HISTO_LENGTH;
+    FeatureVector::iterator f1it = vFeatVec1.begin(), f2it = vFeatVec2.begin();
+    FeatureVector::iterator f1end = vFeatVec1.end(), f2end = vFeatVec2.end();
+    while (f1it != f1end && f2it != f2end) {
+        if (f1it->first == f2it->first) {
+            for (size_t i1 = 0, iend1 = f1it->second.size(); i1 < iend1; i1++) {
+                size_t idx1 = f1it->second[i1];
+                // If there is already a MapPoint skip
+                if (!free1[idx1]) continue;
+                const KpB& kp1 = vKeysUn1[idx1];
+                const uint8_t* d1 = desc1 + idx1 * 32;
+                std::vector<std::pair<int, size_t> > vDistIndex;
+                for (size_t i2 = 0, iend2 = f2it->second.size(); i2 < iend2; i2++) {
+                    size_t idx2 = f2it->second[i2];
+                    // If we have already matched or there is a MapPoint skip
+                    if (vbMatched2[idx2] || !free2[idx2]) continue;
+                    const int dist = orbref_hamming(d1, desc2 + idx2 * 32);
+                    if (dist > BOW_TH_LOW) continue;
+                    vDistIndex.push_back(std::make_pair(dist, idx2));
+                }
+                if (vDistIndex.empty()) continue;
+                std::sort(vDistIndex.begin(), vDistIndex.end());
+                int BestDist = vDistIndex.front().first;
+                int DistTh = std::round(2 * BestDist);
+                for (size_t id = 0; id < vDistIndex.size(); id++) {
+                    if (vDistIndex[id].first > DistTh) break;
+                    int currentIdx2 = (int)vDistIndex[id].second;
+                    const KpB& kp2 = vKeysUn2[currentIdx2];
+                    if (CheckDistEpipolarLine(kp1, kp2, F12, mvLevelSigma2)) {
+                        vbMatched2[currentIdx2] = true;
+                        vMatches12[idx1] = currentIdx2;
+                        nmatches++;
+                        if (mbCheckOrientation) {
+                            float rot = kp1.angle - kp2.angle;
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = std::round(rot * factor);
+                            if (bin == BOW_HISTO_LENGTH) bin = 0;
+                            rotHist[bin].push_back((int)idx1);
+                        }
+                        break;
+                    }
+                }
+            }
+            f1it++;
+            f2it++;
+        } else if (f1it->first < f2it->first) {
+            f1it = vFeatVec1.lower_bound(f2it->first);
+        } else {
+            f2it = vFeatVec2.lower_bound(f1it->first);
+        }
+    }
+    if (mbCheckOrientation) {
+        int32_t sizes[BOW_HISTO_LENGTH], ind[3];
+        for (int i = 0; i < BOW_HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        orbref_three_maxima(sizes, BOW_HISTO_LENGTH, ind);
+        for (int i = 0; i < BOW_HISTO_LENGTH; i++) {
+            if (i == ind[0] || i == ind[1] || i == ind[2]) continue;
+            for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+                vMatches12[rotHist[i][j]] = -1;
+                nmatches--;
+            }
+        }
+    }
+    for (int i = 0; i < n1; i++) matches12[i] = vMatches12[i];
     return nmatches;
 }
 

@@ -99,6 +99,7 @@ def lib():
         L.orbref_sbp_last_frame.argtypes = [vp, vp, i32, vp, vp, f32, f32, f32, f32, vp, vp, vp, vp, i32, vp, vp, f32, i32, vp, vp]
         L.orbref_sbp_keyframe.argtypes = [vp, vp, i32, vp, vp, f32, f32, f32, f32, vp, vp, i32, i32, vp, vp, vp, vp, vp, f32,
                                           i32, i32, vp, vp]
+        L.orbref_search_for_triangulation.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp]
         fuse_args = [vp, vp, i32, vp, f32, f32, f32, f32, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp]
         L.orbref_fuse_pose.argtypes = fuse_args
         L.orbref_fuse_sim3.argtypes = fuse_args
@@ -502,4 +503,20 @@ def search_by_bow_kf_kf(kp1, desc1, valid1, fv1, kp2, desc2, valid2, fv2, nnrati
     n = lib().orbref_search_by_bow_kf_kf(_p(kp1), _p(desc1), len(kp1), _p(valid1), _p(a[0]), _p(a[1]), _p(a[2]), len(a[0]),
                                          _p(kp2), _p(desc2), len(kp2), _p(valid2), _p(b[0]), _p(b[1]), _p(b[2]), len(b[0]),
                                          nnratio, int(check_orientation), _p(out))
+    return n, out[:len(kp1)].copy()
+
+
+def search_for_triangulation(kp1, desc1, free1, fv1, kp2, desc2, free2, fv2, F12, level_sigma2, check_orientation=True):
+    """ORBmatcher::SearchForTriangulation: (nmatches, vMatches12[n1] = index in keyframe 2 or -1).  free1 / free2:
+    the feature holds no map point; F12: 3x3; level_sigma2: mvLevelSigma2 of keyframe 2."""
+    kp1, kp2 = np.ascontiguousarray(kp1, KP_DTYPE), np.ascontiguousarray(kp2, KP_DTYPE)
+    desc1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32)
+    desc2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+    free1, free2 = np.ascontiguousarray(free1, np.uint8), np.ascontiguousarray(free2, np.uint8)
+    a, b = _fv_arrays(fv1), _fv_arrays(fv2)
+    F, s2 = _f32(F12).reshape(9), _f32(level_sigma2)
+    out = np.full(max(len(kp1), 1), -1, np.int32)
+    n = lib().orbref_search_for_triangulation(_p(kp1), _p(desc1), len(kp1), _p(free1), _p(a[0]), _p(a[1]), _p(a[2]), len(a[0]),
+                                              _p(kp2), _p(desc2), len(kp2), _p(free2), _p(b[0]), _p(b[1]), _p(b[2]), len(b[0]),
+                                              _p(F), _p(s2), int(check_orientation), _p(out))
     return n, out[:len(kp1)].copy()

@@ -131,6 +131,9 @@ def lib():
     L.orbhip_search_by_projection_device.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, OrbFrameBounds,
                                                      vp, i32, f32, i32, i32, vp, vp]
     L.orbhip_search_by_projection.argtypes = [vp, vp, vp, i32, vp, vp, i32, OrbFrameBounds, vp, i32, f32, i32, i32, vp, vp]
+    L.orbhip_search_for_triangulation_device.argtypes = [vp] + [vp] * 16 + [i32, i32, i32, vp, vp, i32, i32, vp, vp, vp]
+    L.orbhip_search_for_triangulation.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, i32,
+                                                  vp, vp, i32, i32, vp, vp]
     L.orbhip_best_in_radius_device.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, OrbFrameBounds, vp, vp]
     L.orbhip_best_in_radius.argtypes = [vp, vp, vp, i32, vp, vp, i32, OrbFrameBounds, vp, vp]
     L.orbhip_undistort_keypoints_device.argtypes = [vp, vp, vp, i32, i32, OrbCamera, vp]

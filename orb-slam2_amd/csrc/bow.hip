@@ -356,6 +356,107 @@ __global__ __launch_bounds__(64) void k_bow_match(const uint8_t* __restrict__ de
     if (lane == 0 && count) atomicAdd(&nmatches[f], count);
 }
 
+// SearchForTriangulation (src/ORBmatcher.cc:863-1025): as in k_bow_match one wave per vocabulary node that both
+// keyframes share.  For a feature of keyframe 1 without a map point the reference collects the features of the
+// node in keyframe 2 that are free (no map point, not matched by an earlier feature) and at most TH_LOW away, sorts
+// them by (distance, index) and takes the first one within 2 * the least distance that passes
+// CheckDistEpipolarLine (:139-156).  Here every lane tests its candidates (distance, epipolar line) and the wave
+// reduces two keys: the least (distance, index) overall and the least among those on the epipolar line.
+__global__ __launch_bounds__(64) void k_bow_triangulate(const KpDevB* __restrict__ kp1, const uint8_t* __restrict__ desc1,
+                                                        const uint8_t* __restrict__ free1, const int32_t* __restrict__ fv1_nodes,
+                                                        const int32_t* __restrict__ fv1_start, const int32_t* __restrict__ fv1_feat,
+                                                        const int32_t* __restrict__ fv1_count, const KpDevB* __restrict__ kp2,
+                                                        const uint8_t* __restrict__ desc2, const uint8_t* __restrict__ free2,
+                                                        const int32_t* __restrict__ fv2_nodes, const int32_t* __restrict__ fv2_start,
+                                                        const int32_t* __restrict__ fv2_feat, const int32_t* __restrict__ fv2_count,
+                                                        int cap, int node_cap, const float* __restrict__ F12,
+                                                        const float* __restrict__ level_sigma2, int nlevels,
+                                                        int32_t* __restrict__ matches12, int32_t* __restrict__ matches21,
+                                                        int32_t* __restrict__ nmatches) {
+    __shared__ uint8_t taken[ORBHIP_FRAME_MAX_KEYPOINTS];
+    const int j = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+    if (j >= fv1_count[f]) return;
+    const int node = fv1_nodes[(long long)f * node_cap + j];
+    const int32_t* n2 = fv2_nodes + (long long)f * node_cap;
+    int lo = 0, hi = fv2_count[f];
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (n2[mid] < node) lo = mid + 1;
+        else hi = mid;
+    }
+    if (lo >= fv2_count[f] || n2[lo] != node) return;
+    const int32_t* s1 = fv1_start + (long long)f * (node_cap + 1);
+    const int32_t* s2 = fv2_start + (long long)f * (node_cap + 1);
+    const int32_t* l1 = fv1_feat + (long long)f * cap + s1[j];
+    const int32_t* l2 = fv2_feat + (long long)f * cap + s2[lo];
+    const int len1 = s1[j + 1] - s1[j], len2 = s2[lo + 1] - s2[lo];
+    for (int p = lane; p < len2; p += 64) taken[p] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const uint8_t* f1 = free1 + (long long)f * cap;
+    const uint8_t* f2 = free2 + (long long)f * cap;
+    const uint8_t* d1f = desc1 + (long long)f * cap * 32;
+    const uint8_t* d2f = desc2 + (long long)f * cap * 32;
+    const KpDevB* k1f = kp1 + (long long)f * cap;
+    const KpDevB* k2f = kp2 + (long long)f * cap;
+    const float* F = F12 + (long long)f * 9;
+    int32_t* m12 = matches12 + (long long)f * cap;
+    int32_t* m21 = matches21 + (long long)f * cap;
+    const unsigned long long NONE = 0xffffffffffffffffull;
+    int count = 0;
+    for (int i1 = 0; i1 < len1; i1++) {
+        const int idx1 = l1[i1];
+        if (!f1[idx1]) continue;  // "If there is already a MapPoint skip"
+        const uint4* q = (const uint4*)(d1f + (long long)idx1 * 32);
+        const uint4 q0 = q[0], q1 = q[1];
+        // epipolar line in the second image, l = x1' F12 = [a b c] (:142-144), single precision, no contraction
+        const float x1 = k1f[idx1].x, y1 = k1f[idx1].y;
+        const float a = __fadd_rn(__fadd_rn(__fmul_rn(x1, F[0]), __fmul_rn(y1, F[3])), F[6]);
+        const float b = __fadd_rn(__fadd_rn(__fmul_rn(x1, F[1]), __fmul_rn(y1, F[4])), F[7]);
+        const float c = __fadd_rn(__fadd_rn(__fmul_rn(x1, F[2]), __fmul_rn(y1, F[5])), F[8]);
+        const float den = __fadd_rn(__fmul_rn(a, a), __fmul_rn(b, b));
+        unsigned long long kA = NONE, kB = NONE;
+        for (int p = lane; p < len2; p += 64) {
+            const int idx2 = l2[p];
+            if (taken[p] || !f2[idx2]) continue;  // "If we have already matched or there is a MapPoint skip"
+            const uint4* t = (const uint4*)(d2f + (long long)idx2 * 32);
+            const uint4 ta = t[0], tb = t[1];
+            const int d = __popc(ta.x ^ q0.x) + __popc(ta.y ^ q0.y) + __popc(ta.z ^ q0.z) + __popc(ta.w ^ q0.w) +
+                          __popc(tb.x ^ q1.x) + __popc(tb.y ^ q1.y) + __popc(tb.z ^ q1.z) + __popc(tb.w ^ q1.w);
+            if (d > BOW_TH_LOW) continue;
+            const unsigned long long key = ((unsigned long long)d << 32) | ((unsigned long long)idx2 << 16) | (unsigned)p;
+            kA = key < kA ? key : kA;
+            const KpDevB& k2 = k2f[idx2];
+            const float num = __fadd_rn(__fadd_rn(__fmul_rn(a, k2.x), __fmul_rn(b, k2.y)), c);
+            bool on_line = false;
+            if (den != 0.f) {
+                const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+                const int oct = min(max(k2.octave, 0), nlevels - 1);
+                on_line = (double)dsqr < 3.84 * (double)level_sigma2[oct];
+            }
+            if (on_line) kB = key < kB ? key : kB;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long pA = __shfl_xor(kA, o), pB = __shfl_xor(kB, o);
+            kA = pA < kA ? pA : kA;
+            kB = pB < kB ? pB : kB;
+        }
+        if (kA == NONE || kB == NONE) continue;
+        const int BestDist = (int)(kA >> 32);
+        const int DistTh = 2 * BestDist;  // round(2*BestDist)
+        if ((int)(kB >> 32) > DistTh) continue;
+        if (lane == 0) {
+            const int idx2 = (int)((kB >> 16) & 0xffffu), pos = (int)(kB & 0xffffu);
+            m12[idx1] = idx2;
+            m21[idx2] = idx1;
+            taken[pos] = 1;
+        }
+        count++;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if (lane == 0 && count) atomicAdd(&nmatches[f], count);
+}
+
 __device__ __forceinline__ float bow_round_half_away(float v) {
     const float t = truncf(v);
     return fabsf(__fsub_rn(v, t)) >= 0.5f ? (v < 0.f ? t - 1.f : t + 1.f) : t;
@@ -476,6 +577,40 @@ int orbhip_search_by_bow_device(orbhip_matcher* m, const OrbKeypoint* d_kp1, con
     hipLaunchKernelGGL(k_bow_match, dim3(node_cap, batch), dim3(64), 0, m->stream, d_desc1, d_valid1, d_fv1_nodes, d_fv1_start,
                        d_fv1_feat, d_fv1_count, d_desc2, d_valid2, d_fv2_nodes, d_fv2_start, d_fv2_feat, d_fv2_count, cap,
                        node_cap, nnratio, th_low_inclusive, d_matches12, d_matches21, d_nmatches);
+    if (check_orientation)
+        hipLaunchKernelGGL(k_bow_rot_filter, dim3(batch), dim3(256), 0, m->stream, (const KpDevB*)d_kp1, (const KpDevB*)d_kp2,
+                           d_n1, cap, d_matches12, d_matches21, d_nmatches);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(m->ev1, m->stream));
+    return ORBHIP_OK;
+}
+
+int orbhip_search_for_triangulation_device(orbhip_matcher* m, const OrbKeypoint* d_kp1, const uint8_t* d_desc1,
+                                           const int32_t* d_n1, const uint8_t* d_free1, const int32_t* d_fv1_nodes,
+                                           const int32_t* d_fv1_start, const int32_t* d_fv1_feat, const int32_t* d_fv1_count,
+                                           const OrbKeypoint* d_kp2, const uint8_t* d_desc2, const int32_t* d_n2,
+                                           const uint8_t* d_free2, const int32_t* d_fv2_nodes, const int32_t* d_fv2_start,
+                                           const int32_t* d_fv2_feat, const int32_t* d_fv2_count, int batch, int cap, int node_cap,
+                                           const float* d_F12, const float* d_level_sigma2, int nlevels, int check_orientation,
+                                           int32_t* d_matches12, int32_t* d_matches21, int32_t* d_nmatches) {
+    if (!m) return orb_fail(ORBHIP_EINVAL, "null matcher");
+    if (batch < 0 || cap < 1 || node_cap < 1 || nlevels < 1) return orb_fail(ORBHIP_EINVAL, "bad size");
+    if (cap > ORBHIP_FRAME_MAX_KEYPOINTS) return orb_fail(ORBHIP_ECAP, "cap %d > %d features per frame", cap, ORBHIP_FRAME_MAX_KEYPOINTS);
+    if (batch == 0) return ORBHIP_OK;
+    if (!d_kp1 || !d_desc1 || !d_n1 || !d_free1 || !d_fv1_nodes || !d_fv1_start || !d_fv1_feat || !d_fv1_count || !d_kp2 ||
+        !d_desc2 || !d_n2 || !d_free2 || !d_fv2_nodes || !d_fv2_start || !d_fv2_feat || !d_fv2_count || !d_F12 || !d_level_sigma2 ||
+        !d_matches12 || !d_matches21 || !d_nmatches)
+        return orb_fail(ORBHIP_EINVAL, "null buffer");
+    HIPCHK(hipSetDevice(m->device));
+    (void)hipGetLastError();
+    HIPCHK(hipEventRecord(m->ev0, m->stream));
+    HIPCHK(hipMemsetAsync(d_matches12, 0xff, sizeof(int32_t) * (size_t)batch * cap, m->stream));
+    HIPCHK(hipMemsetAsync(d_matches21, 0xff, sizeof(int32_t) * (size_t)batch * cap, m->stream));
+    HIPCHK(hipMemsetAsync(d_nmatches, 0, sizeof(int32_t) * (size_t)batch, m->stream));
+    hipLaunchKernelGGL(k_bow_triangulate, dim3(node_cap, batch), dim3(64), 0, m->stream, (const KpDevB*)d_kp1, d_desc1, d_free1,
+                       d_fv1_nodes, d_fv1_start, d_fv1_feat, d_fv1_count, (const KpDevB*)d_kp2, d_desc2, d_free2, d_fv2_nodes,
+                       d_fv2_start, d_fv2_feat, d_fv2_count, cap, node_cap, d_F12, d_level_sigma2, nlevels, d_matches12,
+                       d_matches21, d_nmatches);
     if (check_orientation)
         hipLaunchKernelGGL(k_bow_rot_filter, dim3(batch), dim3(256), 0, m->stream, (const KpDevB*)d_kp1, (const KpDevB*)d_kp2,
                            d_n1, cap, d_matches12, d_matches21, d_nmatches);

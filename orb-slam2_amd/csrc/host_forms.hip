@@ -1,5 +1,6 @@
 // Host-pointer forms of the entry points a C++ caller with host-resident data needs besides the
 // windowed / projection matchers: ORBmatcher::SearchByBoW (src/ORBmatcher.cc:158-295, :726-861),
+// ORBmatcher::SearchForTriangulation (:863-1025),
 // MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:191-256), Frame::UndistortKeyPoints
 // (src/Frame.cc:290-320) and the per-feature vocabulary descent behind Frame::ComputeBoW (:281-288).
 // Each copies its arguments into a staging arena of the handle, runs the device entry point on the
@@ -125,6 +126,77 @@ int orbhip_search_by_bow(orbhip_matcher* m, const OrbKeypoint* kp1, const uint8_
     if (rc) return rc;
     if (n1) HIPCHK(hipMemcpyAsync(matches12, b + o_m12, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, m->stream));
     if (n2) HIPCHK(hipMemcpyAsync(matches21, b + o_m21, sizeof(int32_t) * n2, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(nmatches, b + o_nm, sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+    return orbhip_matcher_synchronize(m);
+}
+
+int orbhip_search_for_triangulation(orbhip_matcher* m, const OrbKeypoint* kp1, const uint8_t* desc1, int n1, const uint8_t* free1,
+                                    const int32_t* fv1_nodes, const int32_t* fv1_start, const int32_t* fv1_feat, int fv1_count,
+                                    const OrbKeypoint* kp2, const uint8_t* desc2, int n2, const uint8_t* free2,
+                                    const int32_t* fv2_nodes, const int32_t* fv2_start, const int32_t* fv2_feat, int fv2_count,
+                                    const float* F12, const float* level_sigma2, int nlevels, int check_orientation,
+                                    int32_t* matches12, int32_t* nmatches) {
+    if (!m) return orb_fail(ORBHIP_EINVAL, "null matcher");
+    if (n1 < 0 || n2 < 0 || nlevels < 1) return orb_fail(ORBHIP_EINVAL, "bad size");
+    if (!nmatches || !F12 || !level_sigma2 || (n1 && (!kp1 || !desc1 || !free1 || !matches12)) || (n2 && (!kp2 || !desc2 || !free2)))
+        return orb_fail(ORBHIP_EINVAL, "null buffer");
+    const FvHost fv[2] = {{fv1_nodes, fv1_start, fv1_feat, fv1_count}, {fv2_nodes, fv2_start, fv2_feat, fv2_count}};
+    int rc;
+    if ((rc = check_fv(fv[0], n1, "first FeatureVector")) || (rc = check_fv(fv[1], n2, "second FeatureVector"))) return rc;
+    for (int i = 0; i < n2; i++)
+        if (kp2[i].octave < 0 || kp2[i].octave >= nlevels)
+            return orb_fail(ORBHIP_EINVAL, "keypoint %d of the second keyframe: octave %d of %d levels", i, kp2[i].octave, nlevels);
+    const int cap = std::max(1, std::max(n1, n2));
+    if (cap > ORBHIP_FRAME_MAX_KEYPOINTS) return orb_fail(ORBHIP_ECAP, "%d features > %d per frame", cap, ORBHIP_FRAME_MAX_KEYPOINTS);
+    const int node_cap = std::max(1, std::max(fv1_count, fv2_count));
+    HIPCHK(hipSetDevice(m->device));
+    Arena a;
+    size_t o_kp[2], o_d[2], o_v[2], o_nodes[2], o_start[2], o_feat[2];
+    for (int s = 0; s < 2; s++) {
+        o_kp[s] = a.take(sizeof(OrbKeypoint) * cap);
+        o_d[s] = a.take(32 * (size_t)cap);
+        o_v[s] = a.take(cap);
+        o_nodes[s] = a.take(sizeof(int32_t) * node_cap);
+        o_start[s] = a.take(sizeof(int32_t) * (node_cap + 1));
+        o_feat[s] = a.take(sizeof(int32_t) * cap);
+    }
+    const size_t o_n = a.take(sizeof(int32_t) * 4), o_m12 = a.take(sizeof(int32_t) * cap), o_m21 = a.take(sizeof(int32_t) * cap);
+    const size_t o_nm = a.take(sizeof(int32_t)), o_F = a.take(sizeof(float) * 9), o_s2 = a.take(sizeof(float) * nlevels);
+    if ((rc = reserve_stage(m, a.off))) return rc;
+    char* b = (char*)m->d_stage;
+    const int32_t counts[4] = {n1, n2, fv1_count, fv2_count};
+    HIPCHK(hipMemcpyAsync(b + o_n, counts, sizeof(counts), hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(b + o_F, F12, sizeof(float) * 9, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(b + o_s2, level_sigma2, sizeof(float) * nlevels, hipMemcpyHostToDevice, m->stream));
+    const OrbKeypoint* kp[2] = {kp1, kp2};
+    const uint8_t* desc[2] = {desc1, desc2};
+    const uint8_t* fr[2] = {free1, free2};
+    const int n[2] = {n1, n2};
+    for (int s = 0; s < 2; s++) {
+        if (n[s]) {
+            HIPCHK(hipMemcpyAsync(b + o_kp[s], kp[s], sizeof(OrbKeypoint) * n[s], hipMemcpyHostToDevice, m->stream));
+            HIPCHK(hipMemcpyAsync(b + o_d[s], desc[s], 32 * (size_t)n[s], hipMemcpyHostToDevice, m->stream));
+            HIPCHK(hipMemcpyAsync(b + o_v[s], fr[s], n[s], hipMemcpyHostToDevice, m->stream));
+        }
+        if (fv[s].count) {
+            HIPCHK(hipMemcpyAsync(b + o_nodes[s], fv[s].nodes, sizeof(int32_t) * fv[s].count, hipMemcpyHostToDevice, m->stream));
+            HIPCHK(hipMemcpyAsync(b + o_start[s], fv[s].start, sizeof(int32_t) * (fv[s].count + 1), hipMemcpyHostToDevice, m->stream));
+            if (fv[s].start[fv[s].count])
+                HIPCHK(hipMemcpyAsync(b + o_feat[s], fv[s].feat, sizeof(int32_t) * fv[s].start[fv[s].count], hipMemcpyHostToDevice,
+                                      m->stream));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(m->stream));  // counts[] lives on this stack frame
+    const int32_t* d_n = (const int32_t*)(b + o_n);
+    rc = orbhip_search_for_triangulation_device(
+        m, (const OrbKeypoint*)(b + o_kp[0]), (const uint8_t*)(b + o_d[0]), d_n, (const uint8_t*)(b + o_v[0]),
+        (const int32_t*)(b + o_nodes[0]), (const int32_t*)(b + o_start[0]), (const int32_t*)(b + o_feat[0]), d_n + 2,
+        (const OrbKeypoint*)(b + o_kp[1]), (const uint8_t*)(b + o_d[1]), d_n + 1, (const uint8_t*)(b + o_v[1]),
+        (const int32_t*)(b + o_nodes[1]), (const int32_t*)(b + o_start[1]), (const int32_t*)(b + o_feat[1]), d_n + 3, 1, cap,
+        node_cap, (const float*)(b + o_F), (const float*)(b + o_s2), nlevels, check_orientation, (int32_t*)(b + o_m12),
+        (int32_t*)(b + o_m21), (int32_t*)(b + o_nm));
+    if (rc) return rc;
+    if (n1) HIPCHK(hipMemcpyAsync(matches12, b + o_m12, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipMemcpyAsync(nmatches, b + o_nm, sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
     return orbhip_matcher_synchronize(m);
 }

@@ -307,6 +307,31 @@ class ORBmatcher:
         self._end()
         return nm, m12, m21
 
+    def SearchForTriangulation(self, F1, F2, free1, free2, F12, level_sigma2):
+        """ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:863-1025) for every pair of two FrameBatch objects on
+        which ComputeBoW has run.  free1 / free2: uint8 CUDA tensors [batch, cap], non-zero where the keyframe's feature
+        holds no map point; F12: float32 CUDA tensor [batch, 3, 3]; level_sigma2: float32 CUDA tensor [nlevels]
+        (KeyFrame::GetSigma2).  Returns (nmatches [batch], matches12 [batch, cap] = vMatches12, matches21)."""
+        import torch
+        assert F1.batch == F2.batch and F1.cap == F2.cap and F1.node_cap == F2.node_cap
+        assert F12.is_cuda and F12.dtype == torch.float32 and F12.is_contiguous() and F12.numel() == 9 * F1.batch
+        assert level_sigma2.is_cuda and level_sigma2.dtype == torch.float32 and level_sigma2.is_contiguous()
+        for fr in (free1, free2):
+            assert fr.is_cuda and fr.dtype == torch.uint8 and fr.is_contiguous() and tuple(fr.shape) == (F1.batch, F1.cap)
+        dev = F1.n.device
+        m12 = torch.empty((F1.batch, F1.cap), dtype=torch.int32, device=dev)
+        m21 = torch.empty((F1.batch, F1.cap), dtype=torch.int32, device=dev)
+        nm = torch.empty(F1.batch, dtype=torch.int32, device=dev)
+        self._begin()
+        _lib.check(self._L.orbhip_search_for_triangulation_device(
+            self._h, F1.kp.data_ptr(), F1.desc.data_ptr(), F1.n.data_ptr(), free1.data_ptr(), F1.fv_nodes.data_ptr(),
+            F1.fv_start.data_ptr(), F1.fv_feat.data_ptr(), F1.fv_count.data_ptr(), F2.kp.data_ptr(), F2.desc.data_ptr(),
+            F2.n.data_ptr(), free2.data_ptr(), F2.fv_nodes.data_ptr(), F2.fv_start.data_ptr(), F2.fv_feat.data_ptr(),
+            F2.fv_count.data_ptr(), F1.batch, F1.cap, F1.node_cap, F12.data_ptr(), level_sigma2.data_ptr(),
+            int(level_sigma2.numel()), int(self.mbCheckOrientation), m12.data_ptr(), m21.data_ptr(), nm.data_ptr()))
+        self._end()
+        return nm, m12, m21
+
     def ComputeDistinctiveDescriptors(self, desc, start):
         """MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:191-256) for many map points:
         desc [total, 32] u8 and start [npoints + 1] i32 CUDA tensors (observations of point p are rows

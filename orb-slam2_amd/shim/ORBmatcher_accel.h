@@ -1,8 +1,8 @@
 // The accelerated primitive of the reference's ORBmatcher, with its signature unchanged:
 //   static int ORBmatcher::DescriptorDistance(const cv::Mat &a, const cv::Mat &b)
 // (include/ORBmatcher.h:46, src/ORBmatcher.cc:1805-1821).  In the reference tree the body of that
-// one function is replaced by the single forwarding line below; SearchForTriangulation, the one method without a
-// forwarding body here, keeps its CPU body and calls it as before.  Batched dense matching goes through orbhip_knn2*.
+// one function is replaced by the single forwarding line below; the search methods get the forwarding bodies that
+// follow.  Batched dense matching goes through orbhip_knn2*.
 #ifndef ORBMATCHER_ACCEL_H
 #define ORBMATCHER_ACCEL_H
 #ifdef ORBHIP_SHIM_CV_STUB
@@ -15,6 +15,7 @@
 #include <cmath>
 #include <set>
 #include <stdexcept>
+#include <utility>
 #include <vector>
 
 #include "../../include/orbhip.h"
@@ -691,6 +692,54 @@ struct ORBmatcherAccel {
             throw std::runtime_error(orbhip_last_error());
         for (int i1 = 0; i1 < n1; i1++)
             if (m12[i1] >= 0) vpMatches12[i1] = vpMapPoints2[m12[i1]];
+        return nmatches;
+    }
+
+    // int SearchForTriangulation(KeyFrame *pKF1, KeyFrame* pKF2, cv::Mat F12, vector<cv::KeyPoint> &vMatchedKeys1,
+    //                            vector<cv::KeyPoint> &vMatchedKeys2, vector<pair<size_t, size_t> > &vMatchedPairs)
+    // (include/ORBmatcher.h:79, src/ORBmatcher.cc:863-1025): node pairing, Hamming distances, the epipolar test and
+    // the rotation histogram run on the device; the three output vectors are filled as :1007-1022 do.
+    template <class KeyFrameT>
+    int SearchForTriangulation(KeyFrameT* pKF1, KeyFrameT* pKF2, cv::Mat F12, std::vector<cv::KeyPoint>& vMatchedKeys1,
+                               std::vector<cv::KeyPoint>& vMatchedKeys2, std::vector<std::pair<size_t, size_t> >& vMatchedPairs) {
+        auto vpMapPoints1 = pKF1->GetMapPointMatches();
+        std::vector<cv::KeyPoint> vKeysUn1 = pKF1->GetKeyPointsUn();
+        const std::vector<unsigned char> d1 = packRows(pKF1->GetDescriptors());
+        const FlatFeatureVector fv1(pKF1->GetFeatureVector());
+        auto vpMapPoints2 = pKF2->GetMapPointMatches();
+        std::vector<cv::KeyPoint> vKeysUn2 = pKF2->GetKeyPointsUn();
+        const std::vector<unsigned char> d2 = packRows(pKF2->GetDescriptors());
+        const FlatFeatureVector fv2(pKF2->GetFeatureVector());
+        const int n1 = (int)vKeysUn1.size(), n2 = (int)vKeysUn2.size();
+        std::vector<unsigned char> free1(n1 ? n1 : 1), free2(n2 ? n2 : 1);
+        for (int i = 0; i < n1; i++) free1[i] = !vpMapPoints1[i];
+        for (int i = 0; i < n2; i++) free2[i] = !vpMapPoints2[i];
+        const int nlevels = pKF2->GetScaleLevels();
+        std::vector<float> sigma2(nlevels);
+        for (int l = 0; l < nlevels; l++) sigma2[l] = pKF2->GetSigma2(l);
+        float F[9];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) F[3 * i + j] = F12.template at<float>(i, j);
+        std::vector<int> vMatches12(n1 ? n1 : 1, -1);
+        int nmatches = 0;
+        if (orbhip_search_for_triangulation(handle, (const OrbKeypoint*)vKeysUn1.data(), d1.data(), n1, free1.data(), fv1.nodes.data(),
+                                            fv1.start.data(), fv1.feat.data(), fv1.count(), (const OrbKeypoint*)vKeysUn2.data(),
+                                            d2.data(), n2, free2.data(), fv2.nodes.data(), fv2.start.data(), fv2.feat.data(),
+                                            fv2.count(), F, sigma2.data(), nlevels, mbCheckOrientation, vMatches12.data(),
+                                            &nmatches) != ORBHIP_OK)
+            throw std::runtime_error(orbhip_last_error());
+        vMatchedKeys1.clear();
+        vMatchedKeys1.reserve(nmatches);
+        vMatchedKeys2.clear();
+        vMatchedKeys2.reserve(nmatches);
+        vMatchedPairs.clear();
+        vMatchedPairs.reserve(nmatches);
+        for (size_t i = 0, iend = n1; i < iend; i++) {
+            if (vMatches12[i] < 0) continue;
+            vMatchedKeys1.push_back(vKeysUn1[i]);
+            vMatchedKeys2.push_back(vKeysUn2[vMatches12[i]]);
+            vMatchedPairs.push_back(std::make_pair(i, vMatches12[i]));
+        }
         return nmatches;
     }
 

@@ -107,6 +107,8 @@ struct FakeKeyFrame {
     cv::Mat GetDescriptors() { return descriptors.clone(); }
     std::vector<FakeMapPoint*> GetMapPointMatches() { return mapPoints; }
     DBoW2::FeatureVector GetFeatureVector() { return featVec; }
+    std::vector<float> levelSigma2;
+    float GetSigma2(int nLevel = 1) const { return levelSigma2[nLevel]; }
     // pose, as KeyFrame::SetPose keeps it (src/KeyFrame.cc:102-109)
     cv::Mat Rcw, tcw, Ow;
     void SetPose(const cv::Mat& Tcw) {
@@ -429,6 +431,37 @@ static int matchers_mode(int argc, char** argv) {
         }
         write_blob(out, &nFound, 4);
         write_blob(out, idx.data(), sizeof(int) * n1);
+    } else if (mode == "triangulate") {
+        // blobs: 0 F12 (9 floats), 1 sigma2 per level, 2 int {check_ori}, then per keyframe (3.., 9..): keypoints,
+        // descriptors, free (1 = the feature holds no map point), fv nodes, fv start, fv features
+        ORB_SLAM::ORBmatcherAccel matcher(0.6f, as<int>(in[2])[0] != 0);
+        static FakeMapPoint held;
+        FakeKeyFrame KF[2];
+        for (int s = 0; s < 2; s++) {
+            const int o = 3 + 6 * s;
+            KF[s].keysUn = keypoints(in[o]);
+            KF[s].descriptors = mat_desc(in[o + 1]);
+            const int n = (int)KF[s].keysUn.size();
+            KF[s].mapPoints.assign(n, (FakeMapPoint*)0);
+            for (int i = 0; i < n; i++)
+                if (!in[o + 2][i]) KF[s].mapPoints[i] = &held;
+            KF[s].featVec = feature_vector(in[o + 3], in[o + 4], in[o + 5]);
+            const int nlev = (int)(in[1].size() / 4);
+            KF[s].levelSigma2.assign(as<float>(in[1]), as<float>(in[1]) + nlev);
+            KF[s].scaleFactors.assign(nlev, 1.f);
+        }
+        std::vector<cv::KeyPoint> k1, k2;
+        std::vector<std::pair<size_t, size_t> > pairs;
+        const int nmatches = matcher.SearchForTriangulation(&KF[0], &KF[1], mat_f32(3, 3, as<float>(in[0])), k1, k2, pairs);
+        std::vector<int> flat(pairs.size() * 2 + 1);
+        for (size_t i = 0; i < pairs.size(); i++) {
+            flat[2 * i] = (int)pairs[i].first;
+            flat[2 * i + 1] = (int)pairs[i].second;
+        }
+        write_blob(out, &nmatches, 4);
+        write_blob(out, flat.data(), sizeof(int) * pairs.size() * 2);
+        write_blob(out, k1.empty() ? 0 : &k1[0], k1.size() * sizeof(cv::KeyPoint));
+        write_blob(out, k2.empty() ? 0 : &k2[0], k2.size() * sizeof(cv::KeyPoint));
     } else if (mode == "bow_kf_f" || mode == "bow_kf_kf") {
         // blobs: 0 float {ratio}, 1 int {check_ori}, then per side (2.., 8..): keypoints, descriptors, valid, fv nodes,
         // fv start, fv features

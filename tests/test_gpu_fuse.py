@@ -105,10 +105,11 @@ def test_fuse_host_form_and_shared_best(orb, orbref):
     assert (z_bi == -1).all() and (z_bd == INT_MAX).all()
 
 
-def two_views(orbref, rng, n, w, h, T1, T2, s12):
+def two_views(orbref, rng, n, w, h, T1, T2, s12, pool=None):
     """n world points and two keyframes that see them: camera 1 at T1w, camera 2 at T2w in a world scaled by s12
     (p_c1 = s12 R12 p_c2 + t12).  Per keyframe: keypoints (jittered projections of the points in view, clutter,
-    shuffled), descriptors, and per keypoint the index of its map point (-1 for clutter)."""
+    shuffled), descriptors, and per keypoint the index of its map point (-1 for clutter).  pool: the map points'
+    descriptors are drawn from these rows (many near-equal descriptors) instead of being random."""
     K = (np.float32(520.0), np.float32(515.0), np.float32(w / 2 + 3.5), np.float32(h / 2 - 2.25))
     z = rng.uniform(2.0, 12.0, n)
     x = (rng.uniform(-40, w + 40, n) - K[2]) / K[0] * z
@@ -125,7 +126,7 @@ def two_views(orbref, rng, n, w, h, T1, T2, s12):
     T2s = T2.copy()
     T2s[:3, 3] = (t2 / s12).astype(np.float32)
     world2 = world / s12  # the points as keyframe 2's map holds them
-    mp_desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    mp_desc = rng.integers(0, 256, (n, 32), dtype=np.uint8) if pool is None else pool[rng.integers(0, len(pool), n)].copy()
     level = rng.integers(0, 8, n)
     views = []
     for cam, pts_world in ((cam1, world), (cam2, world2)):

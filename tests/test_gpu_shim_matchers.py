@@ -322,3 +322,33 @@ def test_search_by_sim3_through_the_cpp_body(orb, orbref, tmp_path, n):
     assert np.array_equal(got, np.where(kinds[0] == 3, -3, m12))
     if n >= 1000:
         assert nfound > 200
+
+
+@pytest.mark.parametrize("n", [1500, 0, 1])
+def test_search_for_triangulation_through_the_cpp_body(orb, orbref, synth, tmp_path, n):
+    """ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:863-1025): FeatureVectors and map-point vectors of two
+    stand-in keyframes, the fundamental matrix as a cv::Mat, and the three output vectors."""
+    from test_gpu_triangulation import scene_pair
+    k, L, levelsup = 10, 4, 2
+    parent, desc, weight = synth.synth_vocabulary(k, L, seed=61)
+    ref = orbref.RefVocabulary(parent, desc, weight, L)
+    rng = np.random.default_rng(800 + n)
+    v1, v2, F = scene_pair(orbref, rng, n, desc[rng.integers(1, len(desc), 50)])
+    sigma2 = (SCALE * SCALE).astype(np.float32)
+    n1, n2 = len(v1["kp"]), len(v2["kp"])
+    _, fv1 = ref.transform(v1["desc"], levelsup)
+    _, fv2 = ref.transform(v2["desc"], levelsup)
+    free1, free2 = (rng.random(n1) < 0.85).astype(np.uint8), (rng.random(n2) < 0.85).astype(np.uint8)
+    rn, r12 = orbref.search_for_triangulation(v1["kp"], v1["desc"], free1, fv1, v2["kp"], v2["desc"], free2, fv2, F, sigma2, True)
+    z = np.zeros(0, np.int32)
+    side = lambda v, fr, fv: [v["kp"], v["desc"], fr, fv[0], fv[1], fv[2] if len(fv[2]) else z]  # noqa: E731
+    out = run(tmp_path, "triangulate", [F.reshape(9), sigma2, np.array([1], np.int32)] + side(v1, free1, fv1) + side(v2, free2, fv2))
+    nm = int(np.frombuffer(out[0], np.int32)[0])
+    pairs = np.frombuffer(out[1], np.int32).reshape(-1, 2)
+    k1, k2 = np.frombuffer(out[2], orbref.KP_DTYPE), np.frombuffer(out[3], orbref.KP_DTYPE)
+    i1 = np.nonzero(r12 >= 0)[0]
+    assert nm == rn == len(pairs)
+    assert np.array_equal(pairs[:, 0], i1) and np.array_equal(pairs[:, 1], r12[i1])
+    assert np.array_equal(k1.view(np.uint8), v1["kp"][i1].view(np.uint8)) and np.array_equal(k2.view(np.uint8), v2["kp"][r12[i1]].view(np.uint8))
+    if n >= 1000:
+        assert rn > 100

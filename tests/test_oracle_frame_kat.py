@@ -368,6 +368,40 @@ def test_search_by_sim3_by_hand(orbref):
     assert n == 1 and list(m12) == [1, -1]
 
 
+def test_search_for_triangulation_by_hand(orbref):
+    """F12 = [[0,0,0],[0,0,-1],[0,1,0]]: a = 0, b = 1, c = -y1, so the epipolar line of (x1, y1) is y2 = y1 and
+    dsqr = (y2 - y1)^2, accepted below 3.84 * sigma2[octave of keypoint 2] (src/ORBmatcher.cc:139-156).  All features
+    under node 7; node 3 exists only in keyframe 1 and node 9 only in keyframe 2 (the lower_bound skips of :976-983)."""
+    F = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)
+    sigma2 = np.array([1.0, 1.44], np.float32)
+    kp1 = kps(orbref, [(10, 100), (20, 100), (30, 100), (40, 100)])
+    d1 = np.stack([bits(0), bits(0), bits(0), bits(0)])
+    kp2 = kps(orbref, [(11, 103, 0), (12, 101.9, 0), (13, 102.2, 1), (14, 100, 0), (15, 100, 0)])
+    d2 = np.stack([bits(2), bits(4), bits(4), bits(5), bits(0)])
+    fv1 = ([3, 7], [0, 1, 4], [3, 0, 1, 2])
+    fv2 = ([7, 9], [0, 4, 5], [0, 1, 2, 3, 4])
+    free1, free2 = [1, 1, 0, 1], [1, 1, 1, 1, 1]
+    # feature 0: candidates (2, #0) off the line (dy = 3), (4, #1) on it (1.9^2 = 3.61 < 3.84) -> 0 -> 1.
+    # feature 1: #1 is taken; (2, #0) off, (4, #2) on the line of level 1 (2.2^2 = 4.84 < 5.5296) -> 1 -> 2.
+    # feature 2 holds a map point; feature 3 sits under node 3, which keyframe 2 does not have, although #4 (node 9) is identical.
+    n, m12 = orbref.search_for_triangulation(kp1, d1, free1, fv1, kp2, d2, free2, fv2, F, sigma2, False)
+    assert n == 2 and list(m12) == [1, 2, -1, -1]
+    # with sigma2 = 1 on level 1, #2 is off the line as well; (5, #3) lies beyond DistTh = 2 * 2 and is never tried
+    n, m12 = orbref.search_for_triangulation(kp1, d1, free1, fv1, kp2, d2, free2, fv2, F, np.array([1.0, 1.0], np.float32), False)
+    assert n == 1 and list(m12) == [1, -1, -1, -1]
+    # #0 holds a map point: BestDist = 4, DistTh = 8, and for feature 1 (5, #3) is now inside the bound and on the line
+    n, m12 = orbref.search_for_triangulation(kp1, d1, free1, fv1, kp2, d2, [0, 1, 1, 1, 1], fv2, F, np.array([1.0, 1.0], np.float32),
+                                             False)
+    assert n == 2 and list(m12) == [1, 3, -1, -1]
+    # distances above TH_LOW = 20 are no candidates at all; 20 itself is
+    d2b = np.stack([bits(21), bits(21), bits(21), bits(20), bits(0)])
+    n, m12 = orbref.search_for_triangulation(kp1, d1, free1, fv1, kp2, d2b, free2, fv2, F, sigma2, False)
+    assert n == 1 and list(m12) == [3, -1, -1, -1]
+    # den == 0 (a zero matrix) rejects everything
+    n, m12 = orbref.search_for_triangulation(kp1, d1, free1, fv1, kp2, d2, free2, fv2, np.zeros((3, 3), np.float32), sigma2, False)
+    assert n == 0 and list(m12) == [-1, -1, -1, -1]
+
+
 def test_projection_frame_to_frame_by_hand(orbref):
     """SearchByProjection(F1, F2, windowSize, ...) (src/ORBmatcher.cc:530-605): same-level window, ratio with <=."""
     T = np.eye(4, dtype=np.float32)
