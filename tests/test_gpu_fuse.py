@@ -180,12 +180,12 @@ def test_search_by_sim3(orb, orbref, n, th):
     bi, bd, _ = device_best(orb, [(v2["kp"], v2["desc"]), (v1["kp"], v1["desc"])], bounds, [pr1, pr2], [side[0][4], side[1][4]])
     d1 = np.where(bd[0] <= TH_HIGH, bi[0], -1)
     d2 = np.where(bd[1] <= TH_HIGH, bi[1], -1)
-    assert np.array_equal(d1, vn1) and np.array_equal(d2, vn2)
+    assert np.array_equal(d1, vn1) and np.array_equal(d2, vn2), "vnMatch1 / vnMatch2 differ from the oracle's"
     agree = np.full(len(d1), -1, np.int32)
     for i1, idx2 in enumerate(d1):
         if idx2 >= 0 and d2[idx2] == i1:
             agree[i1] = idx2
-    assert np.array_equal(agree, m12) and int((agree >= 0).sum()) == nfound
+    assert np.array_equal(agree, m12) and int((agree >= 0).sum()) == nfound, "agreement differs from the oracle's"
     if n >= 1000:
         # the pairs that agree are keypoints of the same world point
         ok = agree >= 0

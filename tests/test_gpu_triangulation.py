@@ -72,10 +72,10 @@ def test_search_for_triangulation(orb, orbref, synth, ori):
                                                   F, sigma2, ori)
         assert np.array_equal(r12, m12[f, :n1]), "pair %d: %d entries of vMatches12 differ" % (f, int((r12 != m12[f, :n1]).sum()))
         assert rn == nm[f], "pair %d nmatches" % f
-        assert (m12[f, n1:] == -1).all()
+        assert (m12[f, n1:] == -1).all(), "pair %d: entries past the keyframe's features" % f
         for i1 in np.nonzero(m12[f] >= 0)[0]:
-            assert m21[f, m12[f, i1]] == i1
-        assert (m21[f] >= 0).sum() == (m12[f] >= 0).sum() == nm[f]
+            assert m21[f, m12[f, i1]] == i1, "pair %d: matches21 is not the inverse of matches12" % f
+        assert (m21[f] >= 0).sum() == (m12[f] >= 0).sum() == nm[f], "pair %d: counts" % f
         ok = r12 >= 0
         true_pairs += int((v1["owner"][ok] == v2["owner"][r12[ok]]).sum())
         total += rn

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on the GPU box: the HIP extractor and the Hamming scan against the CPU oracle on
-configurations drawn from a seeded generator, the two windowed matchers on random frame pairs and the five SearchByProjection overloads on reseeded scenes, for
+configurations drawn from a seeded generator, the two windowed matchers on random frame pairs, the five SearchByProjection overloads, both Fuse forms, SearchBySim3 and
+SearchForTriangulation on reseeded scenes, for
 a time budget.  Everything is compared bit for bit (keypoint
 fields including the orientation's float bits, descriptors, kNN indices and distances).  Writes one JSON summary.
    python3 tools/parity_sweep.py [--seconds 240] [--seed 1] [--out gpurun_out/parity_sweep.json]
@@ -70,6 +71,9 @@ def main():
     INT_MAX = 2147483647
     import test_gpu_projection as tp  # scenes, oracle calls and the device-against-oracle comparison of the tests
     pj = {"calls": 0, "mismatching_calls": 0, "failures": []}  # SearchByProjection, all five overloads
+    import test_gpu_fuse as tf
+    import test_gpu_triangulation as tt
+    fm = {"calls": 0, "mismatching_calls": 0, "failures": []}  # Fuse x2, SearchBySim3, SearchForTriangulation
     real_default_rng = np.random.default_rng
     real_run_device = tp.run_device
 
@@ -193,6 +197,19 @@ def main():
                     pj["failures"].append(dict(test=fn.__name__, seed=it_seed, what=str(e)[:200], **kw))
                 except AssertionError:
                     pass  # the tests' own "enough matches" checks are tuned to their fixed seeds, not parity statements
+            # ---- Fuse (both forms), SearchBySim3, SearchForTriangulation: the scenes of their tests under the same seeds ----
+            for fn, kw in ((tf.test_fuse, dict(sim3=False, th=float(rng.choice([2.5, 3.0])), ties=bool(rng.integers(0, 2)))),
+                           (tf.test_fuse, dict(sim3=True, th=4.0, ties=bool(rng.integers(0, 2)))),
+                           (tf.test_search_by_sim3, dict(n=int(rng.choice([60, 700, 1800])), th=float(rng.choice([7.5, 10.0])))),
+                           (tt.test_search_for_triangulation, dict(synth=orb.synth, ori=bool(rng.integers(0, 2))))):
+                fm["calls"] += 1
+                try:
+                    fn(orb, orbref, **kw)
+                except AssertionError as e:
+                    if str(e):  # the parity statements of these tests carry a message, their "enough matches" checks do not
+                        fm["mismatching_calls"] += 1
+                        kw.pop("synth", None)
+                        fm["failures"].append(dict(test=fn.__name__, seed=it_seed, what=str(e)[:200], **kw))
         finally:
             np.random.default_rng = real_default_rng
         if time.time() - last_print > 30:
@@ -200,15 +217,18 @@ def main():
             print("extraction: %d configurations, %d frames, %d mismatching; scans: %d calls, %d mismatching" %
                   (ex["configurations"], ex["frames"], ex["mismatching_frames"], kn["calls"], kn["mismatching_calls"]), flush=True)
     res = {"what": "tools/parity_sweep.py --seconds %g --seed %d: HIP path against the CPU oracle, bit for bit" % (args.seconds, args.seed),
-           "extraction": ex, "hamming_knn2": kn, "windowed_matchers": wm, "search_by_projection": pj}
+           "extraction": ex, "hamming_knn2": kn, "windowed_matchers": wm, "search_by_projection": pj,
+           "fuse_sim3_triangulation": fm}
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, "w") as f:
         json.dump(res, f, indent=1)
     print(json.dumps({"extraction": {k: v for k, v in ex.items() if k != "failures"}, "failures": ex["failures"][:5],
                       "hamming_knn2": {k: v for k, v in kn.items() if k != "failures"}, "knn_failures": kn["failures"][:5],
                       "windowed_matchers": {k: v for k, v in wm.items() if k != "failures"}, "window_failures": wm["failures"][:5],
-                      "search_by_projection": {k: v for k, v in pj.items() if k != "failures"}, "projection_failures": pj["failures"][:5]}))
-    return 1 if ex["mismatching_frames"] or kn["mismatching_calls"] or wm["mismatching_calls"] or pj["mismatching_calls"] else 0
+                      "search_by_projection": {k: v for k, v in pj.items() if k != "failures"}, "projection_failures": pj["failures"][:5],
+                      "fuse_sim3_triangulation": {k: v for k, v in fm.items() if k != "failures"}, "fuse_failures": fm["failures"][:5]}))
+    return 1 if (ex["mismatching_frames"] or kn["mismatching_calls"] or wm["mismatching_calls"] or pj["mismatching_calls"]
+                 or fm["mismatching_calls"]) else 0
 
 
 if __name__ == "__main__":
