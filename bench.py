@@ -760,7 +760,29 @@ def bow_leg(orb, torch, dev, orbref, m):
             "compute_bow_ms_per_%d_frames" % b: round(t_bow * 1e3, 3), "mean_matches_per_pair": round(float(nm.float().mean().item()), 1),
             "cpu_oracle_1_thread_pairs_per_sec": round(1 / ct, 1),
             "parity_pair0": bool(rn == int(nm[0].item()) and np.array_equal(r12, m12[0].cpu().numpy()))}
-    return {"search_by_bow": sbow,
+    # SearchForTriangulation on the same 256 pairs: every feature free, keypoints at the origin and F12 chosen so
+    # that every candidate lies on its epipolar line (the sort-and-walk of the reference then depends on the
+    # distances alone), next to the oracle on one thread for the first pair
+    F12 = np.tile(np.array([0, 0, 0, 0, 0, -1, 0, 1, 0], np.float32), (b, 1))
+    d_F12 = torch.from_numpy(F12).to(cuda)
+    sig = torch.from_numpy((1.2 ** (2 * np.arange(8))).astype(np.float32)).to(cuda)
+    tst = []
+    for _ in range(4):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        nmt, t12, _ = mm.SearchForTriangulation(F1, F2, ones, ones, d_F12, sig)
+        mm.synchronize()
+        tst.append(time.perf_counter() - t0)
+    tt = float(np.median(tst[1:]))
+    t0 = time.perf_counter()
+    rnt, rt12 = orbref.search_for_triangulation(hk, d1[0], np.ones(nf, np.uint8), fv1, hk, d2[0], np.ones(nf, np.uint8), fv2,
+                                                F12[0].reshape(3, 3), sig.cpu().numpy(), True)
+    ctt = time.perf_counter() - t0
+    stri = {"pairs": b, "features": nf, "ms": round(tt * 1e3, 3), "pairs_per_sec": round(b / tt, 1),
+            "mean_matches_per_pair": round(float(nmt.float().mean().item()), 1),
+            "cpu_oracle_1_thread_pairs_per_sec": round(1 / ctt, 1),
+            "parity_pair0": bool(rnt == int(nmt[0].item()) and np.array_equal(rt12, t12[0].cpu().numpy()))}
+    return {"search_by_bow": sbow, "search_for_triangulation": stri,
             "descriptors": n, "tree": "k=%d L=%d (%d nodes, synthetic)" % (k, L, len(parent)), "ms": round(best * 1e3, 3),
             "descriptors_per_sec": float("%.4g" % (n / best)),
             "cpu_oracle_1_thread_descriptors_per_sec": float("%.4g" % (2000 / cdt)), "parity_first_2000": bool(ok)}
@@ -895,6 +917,47 @@ def windowed_leg(orb, torch, dev, orbref):
         "frames": b, "blocking_ms": round(res_chain["blocking"][0] * 1e3, 3), "queued_ms": round(res_chain["queued"][0] * 1e3, 3),
         "queued_frames_per_sec": round(b / res_chain["queued"][0], 1),
         "same_result": bool(torch.equal(res_chain["blocking"][2], res_chain["queued"][2]))}
+    # Fuse / SearchBySim3: the independent best-in-radius search with the same probes (radius 15 * scale, levels
+    # octave-1..octave+1), next to the oracle's Fuse on one thread for the first 4 frames (identity pose, points at
+    # depth 1 projecting onto F1's keypoints); parity on those frames with the probes the oracle built
+    fn = lambda: m_proj.BestInRadius(F2, probes, d1, n)  # noqa: E731
+    fn()
+    ts = []
+    for _ in range(3):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        fn()
+        m_proj.synchronize()
+        ts.append(time.perf_counter() - t0)
+    t_f, ok_f = 0.0, True
+    fprobes = np.zeros((4, nf), orb.PROBE_DTYPE)
+    refs = []
+    for f in range(4):
+        k = int(hn[f])
+        pos = np.stack([hk1[f, :k]["x"], hk1[f, :k]["y"], np.ones(k, np.float32)], 1)
+        dist = np.sqrt((pos.astype(np.float64) ** 2).sum(1))
+        min_d = (dist / sf[hk1[f, :k]["octave"]]).astype(np.float32)
+        nrm = (pos / dist[:, None]).astype(np.float32)
+        t0 = time.perf_counter()
+        r = orbref.fuse(hk2[f, :k], hd2[f, :k], bounds, (1.0, 1.0, 0.0, 0.0), sf, ident, np.zeros(k, np.uint8), pos, nrm, min_d,
+                        min_d * np.float32(4.0), hd1[f, :k], 15.0)
+        t_f += time.perf_counter() - t0
+        fprobes[f, :k] = r[3]
+        refs.append(r)
+    fprobes[:, :]["reserved"] = 0
+    F2s = orb.FrameBatch(m_proj, kp2[:4].contiguous(), d2[:4].contiguous(), n[:4].contiguous(), bounds)
+    bi, bd = m_proj.BestInRadius(F2s, torch.from_numpy(fprobes.view(np.uint8).reshape(4, nf, 32).copy()).to(cuda), d1[:4].contiguous(),
+                                 n[:4].contiguous())
+    m_proj.synchronize()
+    bi, bd = bi.cpu().numpy(), bd.cpu().numpy()
+    for f in range(4):
+        k = int(hn[f])
+        ok_f = ok_f and np.array_equal(bi[f, :k], refs[f][1]) and np.array_equal(bd[f, :k], refs[f][2])
+    out["best_in_radius_th15"] = {
+        "what": "the per-map-point search of ORBmatcher::Fuse / SearchBySim3, one probe per keypoint of the other frame",
+        "frames_per_sec": round(b / float(np.median(ts)), 1), "ms_per_%d_frames" % b: round(float(np.median(ts)) * 1e3, 3),
+        "cpu_oracle_1_thread_frames_per_sec": round(4 / t_f, 1), "parity_first_4_frames": bool(ok_f),
+        "mean_fused_per_frame_first_4": round(float(np.mean([r[0] for r in refs])), 1)}
     out["frame_grid_ms_per_%d_frames" % b] = round(t_grid * 1e3, 3)
     out["cpu_oracle_1_thread_pairs_per_sec"] = {"search_for_initialization_w100": round(4 / t_i, 1),
                                                 "window_search_w100": round(4 / t_w, 1),
