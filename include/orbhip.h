@@ -340,6 +340,40 @@ int orbhip_search_by_projection(orbhip_matcher* m, const OrbProbe* probes, const
                                 const uint8_t* taken, int rule, float nnratio, int th_dist, int check_orientation,
                                 int32_t* match_of_feature, int32_t* nmatches);
 
+/* ---- Probes from poses and map points -------------------------------------------------------------
+ * A camera as the projection matchers use it: rotation, translation and centre of the pose (CV_32F) and the
+ * intrinsics.  orbhip_projection_from_pose fills it from a 4x4 row-major Tcw as Frame::UpdatePoseMatrices
+ * (src/Frame.cc:131-136) and KeyFrame::SetPose (src/KeyFrame.cc:102-109) do (Ow = -Rcw.t()*tcw);
+ * orbhip_projection_from_sim3 decomposes a Sim3 Scw first (src/ORBmatcher.cc:305-310, :1156-1160).  Host
+ * computations. */
+typedef struct OrbProjection {
+    float Rcw[9], tcw[3], Ow[3];
+    float fx, fy, cx, cy;
+} OrbProjection;
+int orbhip_projection_from_pose(const float* Tcw, float fx, float fy, float cx, float cy, OrbProjection* out);
+int orbhip_projection_from_sim3(const float* Scw, float fx, float fy, float cx, float cy, OrbProjection* out);
+#define ORBHIP_PROBES_LAST_FRAME 0 /* SearchByProjection(CurrentFrame, LastFrame, th)  src/ORBmatcher.cc:1531-1556 */
+#define ORBHIP_PROBES_KEYFRAME 1   /* SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist)  :1651-1690 */
+#define ORBHIP_PROBES_FRUSTUM 2    /* Frame::isInFrustum (src/Frame.cc:138-199) + SearchByProjection(F, vpMapPoints, th) :63-81 */
+#define ORBHIP_PROBES_FUSE 3       /* Fuse, both forms (:1054-1094, :1180-1223); SearchByProjection(pKF, Scw, ...) (:326-375) */
+/* Replaces, for `batch` target frames, the lines of those methods between their pointer tests and their
+ * GetFeaturesInArea call: frame f projects its d_npoints[f] map points (world positions d_pos, 3 floats each;
+ * normals d_normal; GetMinDistanceInvariance / GetMaxDistanceInvariance in d_min_dist / d_max_dist; all indexed
+ * f*probe_cap + i) with camera d_cams[f] and writes one OrbProbe per point — valid = 0 where the reference takes a
+ * `continue` (d_skip[f*probe_cap + i] != 0 stands for its pointer tests: NULL, isBad(), outlier, already found).
+ * d_src_kp (LAST_FRAME: LastFrame.mvKeys[i] / mvKeysUn[i]; KEYFRAME: pKF->GetKeyPointUn(i)) supplies the octave and
+ * the angle; th is the method's th (FRUSTUM: the th of SearchByProjection, the radius being
+ * RadiusByViewingCos(viewCos) [* th if th != 1] * scale); viewing_cos_limit is isInFrustum's (0.5 in
+ * src/Tracking.cc).  Arrays a kind does not read may be NULL (LAST_FRAME: normals and distances; KEYFRAME: normals
+ * and d_max_dist).  The probes feed orbhip_search_by_projection_device (LAST_FRAME and KEYFRAME with
+ * ORBHIP_PROJ_BEST, FRUSTUM with ORBHIP_PROJ_LOCAL_MAP, FUSE with ORBHIP_PROJ_BEST for the Sim3 overload) or
+ * orbhip_best_in_radius_device (FUSE).  Device pointers; asynchronous on the matcher's stream. */
+int orbhip_build_probes_device(orbhip_matcher* m, int kind, const OrbProjection* d_cams, OrbFrameBounds bounds,
+                               const float* d_scale_factors, int nlevels, const float* d_pos, const float* d_normal,
+                               const float* d_min_dist, const float* d_max_dist, const OrbKeypoint* d_src_kp,
+                               const uint8_t* d_skip, const int32_t* d_npoints, int batch, int probe_cap, float th,
+                               float viewing_cos_limit, OrbProbe* d_probes);
+
 /* The search the reference's Fuse and SearchBySim3 make per projected map point — "match to the most similar
  * keypoint in the radius" (ORBmatcher::Fuse src/ORBmatcher.cc:1096-1124 and :1225-1253, ORBmatcher::SearchBySim3
  * :1376-1404 and :1461-1489): KeyFrame::GetFeaturesInArea(u, v, r) (src/KeyFrame.cc:638-683), the level test

@@ -433,6 +433,59 @@ int orbref_sbp_local_map(const void* kp, const uint8_t* desc, int n, const int32
     return nmatches;
 }
 
+// Frame::isInFrustum(MapPoint *pMP, float viewingCosLimit), src/Frame.cc:138-199, for npoints map points of one
+// frame with pose Tcw (mRcw, mtcw and mOw = -mRcw.t()*mtcw as Frame::UpdatePoseMatrices keeps them, :131-136).
+// Outputs are the tracking fields the function leaves in the map point: mbTrackInView, mTrackProjX, mTrackProjY,
+// mnTrackScaleLevel, mTrackViewCos (untouched slots stay 0).  Returns the number of points in view.
+int orbref_is_in_frustum(const int32_t bounds[4], float fx, float fy, float cx, float cy, const float* Tcw /*4x4 row-major*/,
+                         const float* mvScaleFactors, int mnScaleLevels, int npoints, const float* pos, const float* normal,
+                         const float* minDistArr, const float* maxDistArr, float viewingCosLimit, uint8_t* mbTrackInView,
+                         float* mTrackProjX, float* mTrackProjY, int32_t* mnTrackScaleLevel, float* mTrackViewCos) {
+    const int mnMinX = bounds[0], mnMinY = bounds[1], mnMaxX = bounds[2], mnMaxY = bounds[3];
+    float mRcw[9], mtcw[3], mOw[3];
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) mRcw[3 * i + j] = Tcw[4 * i + j];
+        mtcw[i] = Tcw[4 * i + 3];
+    }
+    centre(mRcw, mtcw, mOw);
+    int nin = 0;
+    for (int i = 0; i < npoints; i++) {
+        mbTrackInView[i] = 0;
+        mTrackProjX[i] = mTrackProjY[i] = mTrackViewCos[i] = 0.f;
+        mnTrackScaleLevel[i] = 0;
+        const float* P = pos + 3 * i;
+        float Pc[3];
+        rigid(Tcw, P, Pc);
+        const float PcX = Pc[0];
+        const float PcY = Pc[1];
+        const float PcZ = Pc[2];
+        if (PcZ < 0.0) continue;
+        const float invz = 1.0 / PcZ;
+        const float u = fx * PcX * invz + cx;
+        const float v = fy * PcY * invz + cy;
+        if (u < mnMinX || u > mnMaxX) continue;
+        if (v < mnMinY || v > mnMaxY) continue;
+        const float maxDistance = maxDistArr[i];
+        const float minDistance = minDistArr[i];
+        const float PO[3] = {P[0] - mOw[0], P[1] - mOw[1], P[2] - mOw[2]};
+        const float dist = norm3(PO);
+        if (dist < minDistance || dist > maxDistance) continue;
+        float viewCos = dot3(PO, normal + 3 * i) / dist;
+        if (viewCos < viewingCosLimit) continue;
+        float ratio = dist / minDistance;
+        const float* it = std::lower_bound(mvScaleFactors, mvScaleFactors + mnScaleLevels, ratio);
+        int nPredictedLevel = (int)(it - mvScaleFactors);
+        if (nPredictedLevel >= mnScaleLevels) nPredictedLevel = mnScaleLevels - 1;
+        mbTrackInView[i] = 1;
+        mTrackProjX[i] = u;
+        mTrackProjY[i] = v;
+        mnTrackScaleLevel[i] = nPredictedLevel;
+        mTrackViewCos[i] = viewCos;
+        nin++;
+    }
+    return nin;
+}
+
 // SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, vector<MapPoint*> &vpMatched, int th),
 // src/ORBmatcher.cc:297-418.  skip[i]: isBad() or in spAlreadyFound.  matched[idx] != 0: vpMatched[idx] set on entry.
 int orbref_sbp_sim3(const void* kp, const uint8_t* desc, int n, const int32_t bounds[4], float fx, float fy, float cx, float cy,

@@ -100,6 +100,7 @@ def lib():
         L.orbref_sbp_keyframe.argtypes = [vp, vp, i32, vp, vp, f32, f32, f32, f32, vp, vp, i32, i32, vp, vp, vp, vp, vp, f32,
                                           i32, i32, vp, vp]
         L.orbref_search_for_triangulation.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp]
+        L.orbref_is_in_frustum.argtypes = [vp, f32, f32, f32, f32, vp, vp, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp]
         fuse_args = [vp, vp, i32, vp, f32, f32, f32, f32, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp]
         L.orbref_fuse_pose.argtypes = fuse_args
         L.orbref_fuse_sim3.argtypes = fuse_args
@@ -520,3 +521,16 @@ def search_for_triangulation(kp1, desc1, free1, fv1, kp2, desc2, free2, fv2, F12
                                               _p(kp2), _p(desc2), len(kp2), _p(free2), _p(b[0]), _p(b[1]), _p(b[2]), len(b[0]),
                                               _p(F), _p(s2), int(check_orientation), _p(out))
     return n, out[:len(kp1)].copy()
+
+
+def is_in_frustum(bounds, K, Tcw, scale_factors, pos, normal, min_dist, max_dist, viewing_cos_limit=0.5):
+    """Frame::isInFrustum for every map point: (in_view u8, proj_x, proj_y, level i32, view_cos)."""
+    n = len(min_dist)
+    b, sf, T = _bounds(bounds), _f32(scale_factors), _f32(Tcw).reshape(16)
+    inv = np.zeros(max(n, 1), np.uint8)
+    px, py, vc = (np.zeros(max(n, 1), np.float32) for _ in range(3))
+    lv = np.zeros(max(n, 1), np.int32)
+    a = [_f32(pos), _f32(normal), _f32(min_dist), _f32(max_dist)]
+    lib().orbref_is_in_frustum(_p(b), K[0], K[1], K[2], K[3], _p(T), _p(sf), len(sf), n, *[_p(x) for x in a],
+                               float(viewing_cos_limit), _p(inv), _p(px), _p(py), _p(lv), _p(vc))
+    return inv[:n].copy(), px[:n].copy(), py[:n].copy(), lv[:n].copy(), vc[:n].copy()

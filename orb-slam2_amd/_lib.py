@@ -54,6 +54,13 @@ class OrbFrameBounds(C.Structure):
     _fields_ = [("min_x", C.c_int32), ("min_y", C.c_int32), ("max_x", C.c_int32), ("max_y", C.c_int32)]
 
 
+class OrbProjection(C.Structure):
+    """A pose (rotation, translation, camera centre; CV_32F) with the intrinsics: what the projection matchers use of
+    a Frame / KeyFrame (src/Frame.cc:131-136, src/KeyFrame.cc:102-109)."""
+    _fields_ = [("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("Ow", C.c_float * 3), ("fx", C.c_float), ("fy", C.c_float),
+                ("cx", C.c_float), ("cy", C.c_float)]
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -134,6 +141,9 @@ def lib():
     L.orbhip_search_for_triangulation_device.argtypes = [vp] + [vp] * 16 + [i32, i32, i32, vp, vp, i32, i32, vp, vp, vp]
     L.orbhip_search_for_triangulation.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, i32,
                                                   vp, vp, i32, i32, vp, vp]
+    L.orbhip_projection_from_pose.argtypes = [vp, f32, f32, f32, f32, C.POINTER(OrbProjection)]
+    L.orbhip_projection_from_sim3.argtypes = [vp, f32, f32, f32, f32, C.POINTER(OrbProjection)]
+    L.orbhip_build_probes_device.argtypes = [vp, i32, vp, OrbFrameBounds, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, vp]
     L.orbhip_best_in_radius_device.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, OrbFrameBounds, vp, vp]
     L.orbhip_best_in_radius.argtypes = [vp, vp, vp, i32, vp, vp, i32, OrbFrameBounds, vp, vp]
     L.orbhip_undistort_keypoints_device.argtypes = [vp, vp, vp, i32, i32, OrbCamera, vp]

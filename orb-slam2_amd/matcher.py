@@ -193,6 +193,46 @@ class ORBmatcher:
         self._end()
         return nm, out
 
+    PROBES_LAST_FRAME, PROBES_KEYFRAME, PROBES_FRUSTUM, PROBES_FUSE = 0, 1, 2, 3
+
+    @staticmethod
+    def projections(poses, K, sim3=False):
+        """One OrbProjection per 4x4 pose (Tcw, or a Sim3 Scw with sim3=True), as a uint8 CUDA tensor [len(poses), 76]:
+        Rcw, tcw, Ow = -Rcw.t()*tcw and the intrinsics K = (fx, fy, cx, cy)."""
+        import torch
+        L = _lib.lib()
+        arr = (_lib.OrbProjection * max(len(poses), 1))()
+        for i, T in enumerate(poses):
+            t = np.ascontiguousarray(T, dtype=np.float32).reshape(16)
+            f = L.orbhip_projection_from_sim3 if sim3 else L.orbhip_projection_from_pose
+            _lib.check(f(_p(t), float(K[0]), float(K[1]), float(K[2]), float(K[3]), C.byref(arr[i])))
+        raw = np.frombuffer(bytes(arr), np.uint8).reshape(max(len(poses), 1), C.sizeof(_lib.OrbProjection))
+        return torch.from_numpy(raw.copy()).cuda()
+
+    def BuildProbes(self, kind, cams, bounds, scale_factors, pos, npoints, th, normal=None, min_dist=None, max_dist=None,
+                    src_kp=None, skip=None, viewing_cos_limit=0.5):
+        """The lines of the projection matchers between their pointer tests and GetFeaturesInArea, on the device: one
+        OrbProbe per map point (kind: PROBES_LAST_FRAME src/ORBmatcher.cc:1531-1556, PROBES_KEYFRAME :1651-1690,
+        PROBES_FRUSTUM src/Frame.cc:138-199 + :63-81, PROBES_FUSE :1054-1094 / :1180-1223 / :326-375).
+        cams: projections(); pos float32 [batch, pcap, 3]; normal likewise; min_dist / max_dist float32 [batch, pcap];
+        src_kp uint8 [batch, pcap, 28] keypoint records; skip uint8 [batch, pcap]; npoints int32 [batch]; CUDA tensors.
+        Returns the probes as a uint8 tensor [batch, pcap, 32] (PROBE_DTYPE records)."""
+        import torch
+        B, pcap = int(pos.shape[0]), int(pos.shape[1])
+        assert pos.is_cuda and pos.dtype == torch.float32 and pos.is_contiguous() and pos.shape[2] == 3
+        sf = scale_factors if torch.is_tensor(scale_factors) else torch.from_numpy(np.ascontiguousarray(scale_factors, np.float32)).cuda()
+        probes = torch.empty((B, max(pcap, 1), 32), dtype=torch.uint8, device=pos.device)
+        ptr = lambda t: 0 if t is None else t.data_ptr()  # noqa: E731
+        for t in (normal, min_dist, max_dist, src_kp, skip):
+            assert t is None or (t.is_cuda and t.is_contiguous())
+        self._begin()
+        _lib.check(self._L.orbhip_build_probes_device(
+            self._h, int(kind), cams.data_ptr(), _lib.OrbFrameBounds(*map(int, bounds)), sf.data_ptr(), int(sf.numel()),
+            pos.data_ptr(), ptr(normal), ptr(min_dist), ptr(max_dist), ptr(src_kp), ptr(skip), npoints.data_ptr(), B, max(pcap, 1),
+            float(th), float(viewing_cos_limit), probes.data_ptr()))
+        self._end()
+        return probes
+
     def BestInRadius(self, F, probes, probe_desc, nprobes):
         """The per-map-point search of ORBmatcher::Fuse (src/ORBmatcher.cc:1096-1124, :1225-1253) and
         ORBmatcher::SearchBySim3 (:1376-1404, :1461-1489) on a batch of keyframes: GetFeaturesInArea(u, v, r), the

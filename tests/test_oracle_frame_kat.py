@@ -402,6 +402,41 @@ def test_search_for_triangulation_by_hand(orbref):
     assert n == 0 and list(m12) == [-1, -1, -1, -1]
 
 
+def test_is_in_frustum_by_hand(orbref):
+    """Tcw = [I | (0, 0, 0.5)] (camera centre (0, 0, -0.5)), K = (100, 100, 50, 50).  Point (0.5, 0, 1.5) -> camera
+    (0.5, 0, 2) -> (75, 50); PO = (0.5, 0, 2), dist = sqrt(4.25); normal (0, 0, 1) -> viewCos = 2 / sqrt(4.25) = 0.9701;
+    minDistance = dist / 1.3 -> level 2 of (1, 1.2, 1.44)."""
+    sf = np.array([1.0, 1.2, 1.44], np.float32)
+    T = np.eye(4, dtype=np.float32)
+    T[2, 3] = 0.5
+    K = (100.0, 100.0, 50.0, 50.0)
+    dist = np.float32(np.sqrt(4.25))
+    pos = np.array([[0.5, 0, 1.5],      # in view
+                    [0.5, 0, -1.5],     # behind the camera
+                    [11.8, 0, 1.5],     # u = 640 = mnMaxX: the bounds test is closed (u > mnMaxX rejects)
+                    [11.9, 0, 1.5],     # u = 645: outside
+                    [0.5, 0, 1.5],      # too close: dist < minDistance
+                    [0.5, 0, 1.5]],     # far beyond the last level: clamped to level 2
+                   np.float32)
+    normal = np.tile(np.array([0, 0, 1], np.float32), (6, 1))
+    normal[2:4] = np.array([11.8, 0, 2], np.float32) / np.float32(np.sqrt(11.8 ** 2 + 4))  # seen head-on
+    min_d = np.array([dist / np.float32(1.3)] * 4 + [dist * 2, dist / 5], np.float32)
+    max_d = min_d * 100
+    iv, px, py, lv, vc = orbref.is_in_frustum(B640, K, T, sf, pos, normal, min_d, max_d, 0.5)
+    assert list(iv) == [1, 0, 1, 0, 0, 1]
+    assert (px[0], py[0], lv[0]) == (75.0, 50.0, 2) and px[2] == 640.0 and lv[5] == 2
+    assert vc[0] == np.float32(2.0 / np.float64(dist))  # PO.dot(Pn) in double over the distance already rounded to float
+    # the viewing-angle limit
+    iv, _, _, _, _ = orbref.is_in_frustum(B640, K, T, sf, pos[:1], normal[:1], min_d[:1], max_d[:1], 0.98)
+    assert list(iv) == [0]
+    # RadiusByViewingCos: 0.9701 <= 0.998 -> 4.0; th = 1 leaves it, th = 3 multiplies (src/ORBmatcher.cc:63-81)
+    kf = kps(orbref, [(75, 50, 2)])
+    for th, want in ((1.0, np.float32(4.0) * sf[2]), (3.0, np.float32(4.0) * np.float32(3.0) * sf[2])):
+        _, _, probes = orbref.sbp_local_map(kf, bits(0)[None], B640, sf, None, [1], [0], [2], vc[:1], px[:1], py[:1], bits(0)[None], th,
+                                            0.8)
+        assert probes["r"][0] == want and (probes["min_level"][0], probes["max_level"][0]) == (1, 2)
+
+
 def test_projection_frame_to_frame_by_hand(orbref):
     """SearchByProjection(F1, F2, windowSize, ...) (src/ORBmatcher.cc:530-605): same-level window, ratio with <=."""
     T = np.eye(4, dtype=np.float32)
