@@ -112,7 +112,7 @@ def test_frustum_probes_and_the_local_map_search(orb, orbref, th, limit):
     nvalid = check(orb, probes, refs)
     assert nvalid > 1500
     radii = np.concatenate([r["r"][r["valid"] != 0] / SCALE[r["max_level"][r["valid"] != 0]] for r in refs])
-    assert len(np.unique(np.round(radii / (th if th != 1.0 else 1.0), 3))) == 2, "both radii of RadiusByViewingCos occur"
+    assert len(np.unique(np.round(radii / (th if th != 1.0 else 1.0), 3))) == 2  # both radii of RadiusByViewingCos occur
     # the device chain: probes -> search, against the oracle's matches
     F = orb.FrameBatch.from_host(m, [s.kp for s in scenes], [s.desc for s in scenes], scenes[0].bounds)
     pcap = probes.shape[1]

@@ -73,7 +73,8 @@ def main():
     pj = {"calls": 0, "mismatching_calls": 0, "failures": []}  # SearchByProjection, all five overloads
     import test_gpu_fuse as tf
     import test_gpu_triangulation as tt
-    fm = {"calls": 0, "mismatching_calls": 0, "failures": []}  # Fuse x2, SearchBySim3, SearchForTriangulation
+    import test_gpu_probes as tb
+    fm = {"calls": 0, "mismatching_calls": 0, "failures": []}  # Fuse x2, SearchBySim3, SearchForTriangulation, the probe builder
     real_default_rng = np.random.default_rng
     real_run_device = tp.run_device
 
@@ -201,7 +202,12 @@ def main():
             for fn, kw in ((tf.test_fuse, dict(sim3=False, th=float(rng.choice([2.5, 3.0])), ties=bool(rng.integers(0, 2)))),
                            (tf.test_fuse, dict(sim3=True, th=4.0, ties=bool(rng.integers(0, 2)))),
                            (tf.test_search_by_sim3, dict(n=int(rng.choice([60, 700, 1800])), th=float(rng.choice([7.5, 10.0])))),
-                           (tt.test_search_for_triangulation, dict(synth=orb.synth, ori=bool(rng.integers(0, 2))))):
+                           (tt.test_search_for_triangulation, dict(synth=orb.synth, ori=bool(rng.integers(0, 2)))),
+                           (tb.test_last_frame_probes, dict(th=float(rng.choice([7.0, 15.0])))),
+                           (tb.test_keyframe_probes, dict()),
+                           (tb.test_frustum_probes_and_the_local_map_search,
+                            dict(th=float(rng.choice([1.0, 3.0, 5.0])), limit=float(rng.choice([0.5, 0.9])))),
+                           (tb.test_fuse_probes, dict(form=str(rng.choice(["pose", "sim3", "sim3_search"]))))):
                 fm["calls"] += 1
                 try:
                     fn(orb, orbref, **kw)
