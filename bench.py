@@ -895,9 +895,16 @@ def windowed_leg(orb, torch, dev, orbref):
     mq = orb.ORBmatcher(0.9, True, device=dev)
     mq.reserve_candidates(64 << 20)
 
+    # the probes of the chain are built on the device from a pose and map points (identity pose, unit intrinsics,
+    # points at depth 1 over F1's keypoints: the same windows as `probes` above)
+    cams = mq.projections([ident] * b, (1.0, 1.0, 0.0, 0.0))
+    pos = torch.cat([k1f[:, :, 0:2], torch.ones((b, nf, 1), dtype=torch.float32, device=cuda)], 2).contiguous()
+    d_sf = torch.from_numpy(sf).to(cuda)
+
     def chain(mm):
         Fc = orb.FrameBatch.from_images(wl.ext, mm, wl.d_img)
-        return mm.SearchByProjection(Fc, probes, d1, n, orb.ORBmatcher.PROJ_BEST, th_dist=100)
+        pr_c = mm.BuildProbes(orb.ORBmatcher.PROBES_LAST_FRAME, cams, bounds, d_sf, pos, n, 15.0, src_kp=kp1)
+        return mm.SearchByProjection(Fc, pr_c, d1, n, orb.ORBmatcher.PROJ_BEST, th_dist=100)
 
     res_chain = {}
     for name, mm in (("blocking", m_proj), ("queued", mq)):
@@ -916,7 +923,12 @@ def windowed_leg(orb, torch, dev, orbref):
     out["extract_grid_project_chain"] = {
         "frames": b, "blocking_ms": round(res_chain["blocking"][0] * 1e3, 3), "queued_ms": round(res_chain["queued"][0] * 1e3, 3),
         "queued_frames_per_sec": round(b / res_chain["queued"][0], 1),
-        "same_result": bool(torch.equal(res_chain["blocking"][2], res_chain["queued"][2]))}
+        "same_result": bool(torch.equal(res_chain["blocking"][2], res_chain["queued"][2])),
+        "what": "images -> extraction -> grid -> probes from pose and map points -> SearchByProjection, all queued on the device",
+        "device_built_probes_equal_host_built": bool(torch.equal(
+            mq.BuildProbes(orb.ORBmatcher.PROBES_LAST_FRAME, cams, bounds, d_sf, pos, n, 15.0, src_kp=kp1)[:, :, :28]
+            * (torch.arange(nf, device=cuda)[None, :, None] < n[:, None, None]),
+            probes[:, :, :28] * (torch.arange(nf, device=cuda)[None, :, None] < n[:, None, None])))}
     # Fuse / SearchBySim3: the independent best-in-radius search with the same probes (radius 15 * scale, levels
     # octave-1..octave+1), next to the oracle's Fuse on one thread for the first 4 frames (identity pose, points at
     # depth 1 projecting onto F1's keypoints); parity on those frames with the probes the oracle built
