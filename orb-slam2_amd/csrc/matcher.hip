@@ -214,6 +214,7 @@ void orbhip_matcher_destroy(orbhip_matcher* m) {
     if (m->d_stage) hipFree(m->d_stage);
     if (m->d_gather) hipFree(m->d_gather);
     if (m->d_work) hipFree(m->d_work);
+    if (m->d_topk) hipFree(m->d_topk);
     if (m->d_err) hipFree(m->d_err);
     if (m->ev0) hipEventDestroy(m->ev0);
     if (m->ev1) hipEventDestroy(m->ev1);

@@ -28,6 +28,8 @@ struct orbhip_matcher {
     size_t stage_bytes = 0;
     void* d_work = nullptr;  // workspace of the windowed matchers
     size_t work_bytes = 0;
+    void* d_topk = nullptr;  // per probe: its four best candidates and its candidate count (projection matchers)
+    size_t topk_bytes = 0;
     int* d_err = nullptr;  // device error flags (int) + the candidate count a failed reservation needed (int64 at +8), read by orbhip_matcher_synchronize
     int scan_kernel = 0;  // ORBHIP_SCAN_MATRIX / ORBHIP_SCAN_POPCOUNT: which kernel scans the train rows of orbhip_knn2*
     long long cand_reserved = 0;  // > 0: candidate lists of the windowed / projection matchers live in a reservation (asynchronous form)

@@ -816,22 +816,94 @@ int run_matcher(orbhip_matcher* m, int mode, const OrbKeypoint* d_kp1, const uin
     return ORBHIP_OK;
 }
 
-// Resolution of the projection matchers: one wave per target frame walks the probes (projected
-// map points) in order.  A feature of the frame that already holds a map point, on entry or from
-// an earlier probe, is skipped (src/ORBmatcher.cc:94, :389, :578, :1573, :1698).
+// Resolution of the projection matchers, in two stages.  A feature of the frame that already holds a map point,
+// on entry or from an earlier probe, is skipped (src/ORBmatcher.cc:94, :389, :578, :1573, :1698), which makes the
+// walk over the probes sequential — but all an earlier probe can do to a later one is take one of its candidates
+// away.  So stage one (k_probe_topk, all probes in parallel, 16 lanes each) sorts out, per probe, its PK best
+// candidates among the features free on entry, in the reference's order (distance, then position in the
+// GetFeaturesInArea list), and counts its free candidates; stage two (k_resolve_probe, one wave per frame) walks
+// the probes in order and only looks at those few: the first of them still free is the best, the next one the
+// second best.  Only when fewer free ones are left than the rule needs AND the probe has more candidates than the
+// PK listed does the wave scan the probe's whole list as the reference does (rare: it takes that many earlier
+// probes having taken exactly this probe's best candidates).
 //   RULE_LOCAL_MAP  :101-124   best and second with their levels; accepted if best <= TH_HIGH unless
 //                               both are on one level and best > ratio * second
 //   RULE_RATIO      :585-600   (float)best <= (float)second * ratio && best <= TH_HIGH
 //   RULE_BEST       :1580-1590, :1705-1715, :401-413   best <= th_dist
-// LDS: owner of every feature (uint16: free, taken on entry, or probe index), the run buffer, the
-// histogram.
 enum { RULE_LOCAL_MAP = 0, RULE_RATIO = 1, RULE_BEST = 2 };
 #define TAKEN16 0xfffeu
+#define PK 4
+
+// ascending compare-exchange
+__device__ __forceinline__ void cmpx(uint32_t& a, uint32_t& b) {
+    const uint32_t lo = min(a, b), hi = max(a, b);
+    a = lo;
+    b = hi;
+}
+
+// topk[(f*pcap + i)*PK + k] = (distance << 16 | feature) of probe i's k-th best free candidate, KEY32_NONE past the
+// end; nfree[f*pcap + i] = number of its candidates that are free on entry.
+__global__ __launch_bounds__(256) void k_probe_topk(const int32_t* __restrict__ np_arr, int pcap, int cap2,
+                                                    const int32_t* __restrict__ starts, const long long* __restrict__ frame_base,
+                                                    const uint32_t* __restrict__ pairs, const uint8_t* __restrict__ taken,
+                                                    uint32_t* __restrict__ topk, int32_t* __restrict__ nfree) {
+    const int i = (blockIdx.x * 256 + threadIdx.x) / AREA_LPQ, li = threadIdx.x % AREA_LPQ, f = blockIdx.y;
+    const int np = min(max(np_arr[f], 0), pcap);
+    int s = 0, e = 0;
+    if (i < np && frame_base[f] >= 0) {
+        const int32_t* st = starts + (long long)f * (pcap + 1);
+        s = st[i];
+        e = st[i + 1];
+    }
+    const uint32_t* fp = pairs + max(frame_base[f], 0LL);
+    const uint8_t* tk = taken ? taken + (long long)f * cap2 : nullptr;
+    uint32_t k0 = KEY32_NONE, k1 = KEY32_NONE, k2 = KEY32_NONE, k3 = KEY32_NONE;
+    int cnt = 0;
+    for (int p = s + li; p < e; p += AREA_LPQ) {
+        const uint32_t pr = fp[p];
+        if (tk && tk[pr & 0xffffu]) continue;
+        cnt++;
+        uint32_t x = ((pr >> 16) << 13) | (uint32_t)(p - s);  // distance, then position in the list
+        cmpx(k0, x);
+        cmpx(k1, x);
+        cmpx(k2, x);
+        k3 = min(k3, x);
+    }
+    // merge the 16 lanes' sorted quadruples: the four smallest of two sorted quadruples are min(a_i, b_{3-i}), a
+    // bitonic sequence that two exchange stages sort
+#pragma unroll
+    for (int o = AREA_LPQ / 2; o >= 1; o >>= 1) {
+        const uint32_t b0 = (uint32_t)__shfl_xor((int)k0, o), b1 = (uint32_t)__shfl_xor((int)k1, o);
+        const uint32_t b2 = (uint32_t)__shfl_xor((int)k2, o), b3 = (uint32_t)__shfl_xor((int)k3, o);
+        k0 = min(k0, b3);
+        k1 = min(k1, b2);
+        k2 = min(k2, b1);
+        k3 = min(k3, b0);
+        cmpx(k0, k2);
+        cmpx(k1, k3);
+        cmpx(k0, k1);
+        cmpx(k2, k3);
+        cnt += __shfl_xor(cnt, o);
+    }
+    if (i < pcap && li < PK) {
+        const uint32_t key = li == 0 ? k0 : li == 1 ? k1 : li == 2 ? k2 : k3;
+        uint32_t word = KEY32_NONE;
+        if (key != KEY32_NONE) word = ((key >> 13) << 16) | (fp[s + (int)(key & 0x1fffu)] & 0xffffu);
+        topk[((long long)f * pcap + i) * PK + li] = word;
+        if (li == 0) nfree[(long long)f * pcap + i] = cnt;
+    }
+}
+
+// Stage two takes the probes of a frame 64 at a time, one per lane, each as if it were the next one; a probe whose
+// listed candidates include a feature that an earlier probe of the same pass takes (or that needs the full scan) ends
+// the pass: the probes before it are settled, it is resolved by the whole wave, and the rest of the chunk goes again.
+// LDS: owner of every feature (uint16: free, taken on entry, or probe index), the claims of a pass, the histogram.
 template <int RULE>
 __global__ __launch_bounds__(64) void k_resolve_probe(const OrbProbe* __restrict__ probes, const int32_t* __restrict__ np_arr,
                                                       int pcap, const KpDev* __restrict__ kp2, const int32_t* __restrict__ n2_arr,
                                                       int cap2, const int32_t* __restrict__ starts,
                                                       const long long* __restrict__ frame_base, const uint32_t* __restrict__ pairs,
+                                                      const uint32_t* __restrict__ topk, const int32_t* __restrict__ nfree,
                                                       const uint8_t* __restrict__ taken, float ratio, int th_dist, int check_ori,
                                                       int32_t* __restrict__ matches_out, int32_t* __restrict__ nmatches_out) {
     extern __shared__ uint16_t lds16[];
@@ -840,80 +912,134 @@ __global__ __launch_bounds__(64) void k_resolve_probe(const OrbProbe* __restrict
     const int f = blockIdx.x, lane = threadIdx.x;
     const int np = min(max(np_arr[f], 0), pcap), n2 = min(max(n2_arr[f], 0), cap2);
     uint16_t* owner = lds16;
-    const int cap2e = (cap2 + 1) & ~1;
-    uint32_t* cbuf = (uint32_t*)(lds16 + cap2e);
-    for (int i = lane; i < cap2; i += 64) owner[i] = (taken && i < n2 && taken[(long long)f * cap2 + i]) ? TAKEN16 : NONE16;
+    uint32_t* claim = (uint32_t*)(lds16 + ((cap2 + 1) & ~1));  // per feature: lowest lane of the current pass that takes it
+    for (int i = lane; i < cap2; i += 64) {
+        owner[i] = (taken && i < n2 && taken[(long long)f * cap2 + i]) ? TAKEN16 : NONE16;
+        claim[i] = KEY32_NONE;
+    }
     if (lane < HISTO_LENGTH + 2) hist[lane] = 0;
     wave_fence();
     const int32_t* st = starts + (long long)f * (pcap + 1);
-    const uint32_t* fp = pairs + frame_base[f];
+    const uint32_t* fp = pairs + max(frame_base[f], 0LL);
     const KpDev* k2f = kp2 + (long long)f * cap2;
     const OrbProbe* pf = probes + (long long)f * pcap;
+    const uint4* tkf = (const uint4*)(topk + (long long)f * pcap * PK);
+    const int32_t* nff = nfree + (long long)f * pcap;
+    const bool need2 = RULE != RULE_BEST;
+    // the acceptance rule of the overload on the best / second-best words (distance << 16 | feature)
+    auto accepts = [&](uint32_t b1, uint32_t b2) -> bool {
+        const int bestDist = (int)(b1 >> 16);
+        if (RULE == RULE_LOCAL_MAP) {
+            bool accept = bestDist <= TH_HIGH;
+            if (accept && b2 != KEY32_NONE) {
+                const int bestDist2 = (int)(b2 >> 16);
+                if (k2f[b1 & 0xffffu].octave == k2f[b2 & 0xffffu].octave && (float)bestDist > __fmul_rn(ratio, (float)bestDist2))
+                    accept = false;
+            }
+            return accept;
+        } else if (RULE == RULE_RATIO) {
+            const float fBest2 = b2 == KEY32_NONE ? (float)INT_MAX : (float)(int)(b2 >> 16);
+            return (float)bestDist <= __fmul_rn(fBest2, ratio) && bestDist <= TH_HIGH;
+        }
+        return bestDist <= th_dist;
+    };
     int nmatches = 0;
     for (int c0 = 0; c0 < np; c0 += 64) {
-        const int ci = min(c0 + lane, np);
-        const int my_s = st[ci], my_e = st[min(ci + 1, pcap)];
+        const int ci = min(c0 + lane, np - 1);
+        const uint4 my = tkf[ci];  // the probe's best free candidates, best first
+        const uint32_t w[PK] = {my.x, my.y, my.z, my.w};
+        const bool listed_all = nff[ci] <= PK;
         const int chunk = min(64, np - c0);
-        int j0 = 0;
-        while (j0 < chunk) {
-            const int S = __shfl(my_s, j0);
-            const unsigned long long fit = __ballot(lane >= j0 && lane < chunk && my_e - S <= RB_CAP);
-            const int q = __popcll(fit);
-            const bool buffered = q > 0;
-            const int jn = buffered ? j0 + q : j0 + 1;
-            if (buffered) {
-                const int E = __shfl(my_e, jn - 1);
-                for (int p = S + lane; p < E; p += 64) cbuf[p - S] = fp[p];
-                wave_fence();
+        int cur = 0;  // probes c0 .. c0 + cur - 1 of the chunk are settled
+        while (cur < chunk) {
+            // ---- every unsettled probe of the chunk at once, one per lane, as if it were the next one ----
+            const bool live = lane >= cur && lane < chunk;
+            uint32_t b1 = KEY32_NONE, b2 = KEY32_NONE;
+            int nf = 0, last = PK - 1;  // last: the listed candidates after it cannot change this probe's outcome
+            if (live) {
+#pragma unroll
+                for (int k = 0; k < PK; k++) {
+                    if (w[k] != KEY32_NONE && owner[w[k] & 0xffffu] == NONE16) {
+                        if (nf == 0) {
+                            b1 = w[k];
+                            if (!need2) last = k;
+                        } else if (nf == 1) {
+                            b2 = w[k];
+                            last = k;
+                        }
+                        nf++;
+                    }
+                }
             }
-            for (int j = j0; j < jn; j++) {
-                const int ip = c0 + j;
-                const int s = __shfl(my_s, j), e = __shfl(my_e, j);
-                if (s >= e) continue;
-                uint32_t k1 = KEY32_NONE, k2 = KEY32_NONE;
-                for (int b = s; b < e; b += 64) {
-                    const int p = b + lane;
-                    if (p < e) {
-                        const uint32_t pr = buffered ? cbuf[p - S] : fp[p];
-                        const uint32_t i2 = pr & 0xffffu, dist = pr >> 16;
-                        if (owner[i2] == NONE16) {
-                            const uint32_t key = (dist << 13) | (uint32_t)(p - s);
-                            k2 = min(max(k1, key), k2);
-                            k1 = min(k1, key);
+            // too few of the listed candidates left and more in the list: this probe needs the full scan
+            bool alone = live && (nf == 0 || (need2 && nf < 2)) && !listed_all;
+            const bool take = live && !alone && b1 != KEY32_NONE && accepts(b1, b2);
+            // an earlier probe of the chunk that takes one of this probe's listed candidates changes its outcome:
+            // every taker claims its feature with its lane number, the lowest lane wins the claim
+            if (take) atomicMin(&claim[b1 & 0xffffu], (uint32_t)lane);
+            wave_fence();
+            if (live && !alone) {
+#pragma unroll
+                for (int k = 0; k < PK; k++)
+                    if (k <= last && w[k] != KEY32_NONE && claim[w[k] & 0xffffu] < (uint32_t)lane) alone = true;
+            }
+            const unsigned long long amask = __ballot(alone);
+            const int stop = amask ? __ffsll((long long)amask) - 1 : chunk;  // probes before it are settled by this pass
+            wave_fence();
+            if (take) claim[b1 & 0xffffu] = KEY32_NONE;
+            const bool commit = take && lane < stop;
+            if (commit) owner[b1 & 0xffffu] = (uint16_t)(c0 + lane);
+            nmatches += __popcll(__ballot(commit));
+            wave_fence();
+            cur = stop;
+            if (cur >= chunk) break;
+            // ---- probe `cur` on its own, by the whole wave, as the reference does ----
+            {
+                const int j = cur, ip = c0 + j;
+                uint32_t s1w = KEY32_NONE, s2w = KEY32_NONE;
+                // its listed candidates first (lanes 0 .. PK-1 look one owner up each); the whole list only if too
+                // few of them are left and there are more
+                const uint32_t v0 = (uint32_t)__builtin_amdgcn_readlane((int)my.x, j), v1 = (uint32_t)__builtin_amdgcn_readlane((int)my.y, j);
+                const uint32_t v2 = (uint32_t)__builtin_amdgcn_readlane((int)my.z, j), v3 = (uint32_t)__builtin_amdgcn_readlane((int)my.w, j);
+                const bool all_listed = __builtin_amdgcn_readlane((int)listed_all, j) != 0;
+                const uint32_t word = lane == 0 ? v0 : lane == 1 ? v1 : lane == 2 ? v2 : v3;
+                const bool is_free = lane < PK && word != KEY32_NONE && owner[word & 0xffffu] == NONE16;
+                const uint32_t fmask = (uint32_t)__ballot(is_free) & ((1u << PK) - 1u);
+                const int nfj = __popc(fmask);
+                if ((nfj == 0 || (need2 && nfj < 2)) && !all_listed) {
+                    const int s = st[ip], e = st[ip + 1];
+                    uint32_t k1 = KEY32_NONE, k2 = KEY32_NONE;
+                    for (int bb = s; bb < e; bb += 64) {
+                        const int p = bb + lane;
+                        if (p < e) {
+                            const uint32_t pr = fp[p];
+                            if (owner[pr & 0xffffu] == NONE16) {
+                                const uint32_t key = ((pr >> 16) << 13) | (uint32_t)(p - s);
+                                k2 = min(max(k1, key), k2);
+                                k1 = min(k1, key);
+                            }
                         }
                     }
-                }
-                uint32_t b1, b2;
-                wave_two_smallest32(k1, k2, b1, b2);
-                if (b1 == KEY32_NONE) continue;
-                const int bestDist = (int)(b1 >> 13);
-                const int bpos = s + (int)(b1 & 0x1fffu);
-                const int bestIdx = (int)((buffered ? cbuf[bpos - S] : fp[bpos]) & 0xffffu);
-                bool accept;
-                if (RULE == RULE_LOCAL_MAP) {
-                    accept = bestDist <= TH_HIGH;
-                    if (accept && b2 != KEY32_NONE) {
-                        const int spos = s + (int)(b2 & 0x1fffu);
-                        const int secondIdx = (int)((buffered ? cbuf[spos - S] : fp[spos]) & 0xffffu);
-                        const int bestDist2 = (int)(b2 >> 13);
-                        if (k2f[bestIdx].octave == k2f[secondIdx].octave && (float)bestDist > __fmul_rn(ratio, (float)bestDist2))
-                            accept = false;
+                    uint32_t s1, s2;
+                    wave_two_smallest32(k1, k2, s1, s2);
+                    if (s1 != KEY32_NONE) s1w = ((s1 >> 13) << 16) | (fp[s + (int)(s1 & 0x1fffu)] & 0xffffu);
+                    if (s2 != KEY32_NONE) s2w = ((s2 >> 13) << 16) | (fp[s + (int)(s2 & 0x1fffu)] & 0xffffu);
+                } else if (nfj > 0) {
+                    const int first = __ffs(fmask) - 1;
+                    s1w = first == 0 ? v0 : first == 1 ? v1 : first == 2 ? v2 : v3;
+                    const uint32_t rest = fmask & (fmask - 1u);
+                    if (rest) {
+                        const int second = __ffs(rest) - 1;
+                        s2w = second == 1 ? v1 : second == 2 ? v2 : v3;
                     }
-                } else if (RULE == RULE_RATIO) {
-                    const float fBest2 = b2 == KEY32_NONE ? (float)INT_MAX : (float)(int)(b2 >> 13);
-                    accept = (float)bestDist <= __fmul_rn(fBest2, ratio) && bestDist <= TH_HIGH;
-                } else {
-                    accept = bestDist <= th_dist;
                 }
-                if (accept) {
-                    wave_fence();
-                    if (lane == 0) owner[bestIdx] = (uint16_t)ip;
+                if (s1w != KEY32_NONE && accepts(s1w, s2w)) {
+                    if (lane == 0) owner[s1w & 0xffffu] = (uint16_t)ip;
                     nmatches++;
-                    wave_fence();
                 }
+                wave_fence();
+                cur = j + 1;
             }
-            wave_fence();  // the buffer is reused by the next run
-            j0 = jn;
         }
     }
     wave_fence();
@@ -1069,11 +1195,26 @@ int orbhip_search_by_projection_device(orbhip_matcher* m, const OrbProbe* d_prob
     Candidates c;
     if ((rc = build_candidates(m, s, d_probe_desc, (const KpDev*)d_kp2, d_desc2, d_cell_start2, d_cell_items2, batch, cap, gg, c)))
         return rc;
-    const size_t lds = sizeof(uint16_t) * (size_t)((cap + 1) & ~1) + sizeof(uint32_t) * RB_CAP;
+    // per probe: PK candidate words and the count of its free candidates
+    const size_t tk_words = (size_t)batch * probe_cap * (PK + 1);
+    if (sizeof(uint32_t) * tk_words > m->topk_bytes) {
+        HIPCHK(hipStreamSynchronize(m->stream));
+        if (m->d_topk) (void)hipFree(m->d_topk);
+        m->d_topk = nullptr;
+        m->topk_bytes = 0;
+        if (hipMalloc(&m->d_topk, sizeof(uint32_t) * tk_words) != hipSuccess)
+            return orb_fail(ORBHIP_ENOMEM, "hipMalloc of %zu bytes failed", sizeof(uint32_t) * tk_words);
+        m->topk_bytes = sizeof(uint32_t) * tk_words;
+    }
+    uint32_t* d_topk = (uint32_t*)m->d_topk;
+    int32_t* d_nfree = (int32_t*)(d_topk + (size_t)batch * probe_cap * PK);
+    hipLaunchKernelGGL(k_probe_topk, dim3((unsigned)(((long long)probe_cap * AREA_LPQ + 255) / 256), batch), dim3(256), 0, m->stream,
+                       d_nprobes, probe_cap, cap, c.starts, c.d_base, c.pairs, d_taken, d_topk, d_nfree);
+    const size_t lds = sizeof(uint16_t) * (size_t)((cap + 1) & ~1) + sizeof(uint32_t) * (size_t)cap;
 #define LAUNCH_PROBE(R)                                                                                                   \
     hipLaunchKernelGGL(k_resolve_probe<R>, dim3(batch), dim3(64), lds, m->stream, d_probes, d_nprobes, probe_cap,          \
-                       (const KpDev*)d_kp2, d_n2, cap, c.starts, c.d_base, c.pairs, d_taken, nnratio, th_dist,              \
-                       check_orientation, d_match_of_feature, d_nmatches)
+                       (const KpDev*)d_kp2, d_n2, cap, c.starts, c.d_base, c.pairs, d_topk, d_nfree, d_taken, nnratio,      \
+                       th_dist, check_orientation, d_match_of_feature, d_nmatches)
     if (rule == ORBHIP_PROJ_LOCAL_MAP) LAUNCH_PROBE(RULE_LOCAL_MAP);
     else if (rule == ORBHIP_PROJ_RATIO) LAUNCH_PROBE(RULE_RATIO);
     else LAUNCH_PROBE(RULE_BEST);
