@@ -261,8 +261,9 @@ int orbhip_features_in_area_device(orbhip_matcher* m, const OrbKeypoint* d_kp, c
 #define ORBHIP_SCAN_POPCOUNT 1
 int orbhip_matcher_set_scan_kernel(orbhip_matcher* m, int kind);
 
-/* Asynchronous form of the windowed and projection matchers below (orbhip_search_for_initialization_device,
- * orbhip_window_search_device, orbhip_search_by_projection_device).  Their candidate lists (one 4-byte record per
+/* Asynchronous form of the two windowed matchers below (orbhip_search_for_initialization_device,
+ * orbhip_window_search_device; the projection matchers keep no candidate lists and are always asynchronous).  Their
+ * candidate lists (one 4-byte record per
  * feature that a GetFeaturesInArea call returns) live in a workspace of the handle.  Without a reservation
  * (entries = 0, the default) each call sizes that workspace from a count it reads back from the device, and
  * blocks.  With a reservation of `entries` records the calls read nothing back and return as soon as their
@@ -323,8 +324,9 @@ typedef struct OrbProbe {
  * or assigned by an earlier probe — Hamming distances, acceptance by `rule`, and for
  * check_orientation != 0 the rotation histogram / three-maxima filter over the new matches.
  * Output d_match_of_feature (batch*cap): the probe assigned to each feature by this call or -1;
- * d_nmatches (batch).  probe_cap <= ORBHIP_MAX_PROBES.  Blocking (sizes a workspace from a device
- * count) unless a reservation is in place. */
+ * d_nmatches (batch).  probe_cap <= ORBHIP_MAX_PROBES.  Asynchronous on the matcher's stream: no candidate
+ * lists are stored (per probe its four best free candidates; a probe that loses them to earlier probes has its
+ * area enumerated again), nothing is read back. */
 int orbhip_search_by_projection_device(orbhip_matcher* m, const OrbProbe* d_probes, const uint8_t* d_probe_desc,
                                        const int32_t* d_nprobes, int probe_cap, const OrbKeypoint* d_kp2,
                                        const uint8_t* d_desc2, const int32_t* d_n2, const int32_t* d_cell_start2,

@@ -819,13 +819,14 @@ int run_matcher(orbhip_matcher* m, int mode, const OrbKeypoint* d_kp1, const uin
 // Resolution of the projection matchers, in two stages.  A feature of the frame that already holds a map point,
 // on entry or from an earlier probe, is skipped (src/ORBmatcher.cc:94, :389, :578, :1573, :1698), which makes the
 // walk over the probes sequential — but all an earlier probe can do to a later one is take one of its candidates
-// away.  So stage one (k_probe_topk, all probes in parallel, 16 lanes each) sorts out, per probe, its PK best
-// candidates among the features free on entry, in the reference's order (distance, then position in the
-// GetFeaturesInArea list), and counts its free candidates; stage two (k_resolve_probe, one wave per frame) walks
-// the probes in order and only looks at those few: the first of them still free is the best, the next one the
-// second best.  Only when fewer free ones are left than the rule needs AND the probe has more candidates than the
-// PK listed does the wave scan the probe's whole list as the reference does (rare: it takes that many earlier
-// probes having taken exactly this probe's best candidates).
+// away.  So stage one (k_probe_topk, all probes in parallel, 16 lanes each) enumerates the probe's area as
+// GetFeaturesInArea does and keeps, per probe, its PK best candidates among the features free on entry, in the
+// reference's order (distance, then position in the list), and the count of its free candidates; stage two
+// (k_resolve_probe, one wave per frame) walks the probes in order and only looks at those few: the first of them
+// still free is the best, the next one the second best.  Only when fewer free ones are left than the rule needs
+// AND the probe has more candidates than the PK listed does the wave enumerate the probe's area again and scan it
+// as the reference does (rare: it takes that many earlier probes having taken exactly this probe's best candidates).
+// No candidate lists are stored.
 //   RULE_LOCAL_MAP  :101-124   best and second with their levels; accepted if best <= TH_HIGH unless
 //                               both are on one level and best > ratio * second
 //   RULE_RATIO      :585-600   (float)best <= (float)second * ratio && best <= TH_HIGH
@@ -835,62 +836,82 @@ enum { RULE_LOCAL_MAP = 0, RULE_RATIO = 1, RULE_BEST = 2 };
 #define PK 4
 
 // ascending compare-exchange
-__device__ __forceinline__ void cmpx(uint32_t& a, uint32_t& b) {
-    const uint32_t lo = min(a, b), hi = max(a, b);
+__device__ __forceinline__ void cmpx64(unsigned long long& a, unsigned long long& b) {
+    const unsigned long long lo = a < b ? a : b, hi = a < b ? b : a;
     a = lo;
     b = hi;
 }
 
-// topk[(f*pcap + i)*PK + k] = (distance << 16 | feature) of probe i's k-th best free candidate, KEY32_NONE past the
-// end; nfree[f*pcap + i] = number of its candidates that are free on entry.
-__global__ __launch_bounds__(256) void k_probe_topk(const int32_t* __restrict__ np_arr, int pcap, int cap2,
-                                                    const int32_t* __restrict__ starts, const long long* __restrict__ frame_base,
-                                                    const uint32_t* __restrict__ pairs, const uint8_t* __restrict__ taken,
-                                                    uint32_t* __restrict__ topk, int32_t* __restrict__ nfree) {
+__device__ __forceinline__ int hamming256(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1) {
+    return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) +
+           __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+// Candidate keys of the projection matchers: distance, then position in the GetFeaturesInArea list (the order in
+// which the reference's strict "<" keeps candidates), with the feature index riding along in the low bits.
+#define PKEY_NONE 0xffffffffffffffffull
+__device__ __forceinline__ unsigned long long pkey(int dist, int pos, int i2) {
+    return ((unsigned long long)dist << 29) | ((unsigned long long)pos << 16) | (unsigned)i2;
+}
+__device__ __forceinline__ uint32_t pkey_word(unsigned long long k) {  // distance << 16 | feature
+    return k == PKEY_NONE ? KEY32_NONE : (uint32_t)((k >> 29) << 16) | (uint32_t)(k & 0xffffu);
+}
+
+// topk[(f*pcap + i)*PK + k] = (distance << 16 | feature) of probe i's k-th best candidate among the features free on
+// entry, KEY32_NONE past the end; nfree[f*pcap + i] = number of its candidates that are free on entry.  The probe's
+// area is enumerated as GetFeaturesInArea walks it; nothing is stored but these five words.
+__global__ __launch_bounds__(256) void k_probe_topk(QuerySource s, const KpDev* __restrict__ kp2,
+                                                    const int32_t* __restrict__ cell_start,
+                                                    const int32_t* __restrict__ cell_items, int cap2, GridGeom gg,
+                                                    const uint8_t* __restrict__ desc1, const uint8_t* __restrict__ desc2,
+                                                    const uint8_t* __restrict__ taken, uint32_t* __restrict__ topk,
+                                                    int32_t* __restrict__ nfree) {
     const int i = (blockIdx.x * 256 + threadIdx.x) / AREA_LPQ, li = threadIdx.x % AREA_LPQ, f = blockIdx.y;
-    const int np = min(max(np_arr[f], 0), pcap);
-    int s = 0, e = 0;
-    if (i < np && frame_base[f] >= 0) {
-        const int32_t* st = starts + (long long)f * (pcap + 1);
-        s = st[i];
-        e = st[i + 1];
+    AreaQuery q;
+    q.active = false;
+    q.x = q.y = q.r = 0.f;
+    q.min_level = q.max_level = -1;
+    if (i < s.nq) q = make_query(s, f, i);
+    uint4 d1a = make_uint4(0, 0, 0, 0), d1b = d1a;
+    if (q.active) {
+        const uint4* d1 = (const uint4*)(desc1 + ((long long)f * s.nq + i) * 32);
+        d1a = d1[0];
+        d1b = d1[1];
     }
-    const uint32_t* fp = pairs + max(frame_base[f], 0LL);
+    const uint8_t* d2f = desc2 + (long long)f * cap2 * 32;
     const uint8_t* tk = taken ? taken + (long long)f * cap2 : nullptr;
-    uint32_t k0 = KEY32_NONE, k1 = KEY32_NONE, k2 = KEY32_NONE, k3 = KEY32_NONE;
+    unsigned long long k0 = PKEY_NONE, k1 = PKEY_NONE, k2 = PKEY_NONE, k3 = PKEY_NONE;
     int cnt = 0;
-    for (int p = s + li; p < e; p += AREA_LPQ) {
-        const uint32_t pr = fp[p];
-        if (tk && tk[pr & 0xffffu]) continue;
-        cnt++;
-        uint32_t x = ((pr >> 16) << 13) | (uint32_t)(p - s);  // distance, then position in the list
-        cmpx(k0, x);
-        cmpx(k1, x);
-        cmpx(k2, x);
-        k3 = min(k3, x);
-    }
+    area_group<true>(gg, kp2 + (long long)f * cap2, cell_start + (long long)f * (GRID_CELLS + 1), cell_items + (long long)f * cap2, q,
+                     li, 0, [&](int i2, int pos) {
+                         if (tk && tk[i2]) return;
+                         cnt++;
+                         const uint4* t = (const uint4*)(d2f + (long long)i2 * 32);
+                         unsigned long long x = pkey(hamming256(t[0], t[1], d1a, d1b), pos, i2);
+                         cmpx64(k0, x);
+                         cmpx64(k1, x);
+                         cmpx64(k2, x);
+                         k3 = x < k3 ? x : k3;
+                     });
     // merge the 16 lanes' sorted quadruples: the four smallest of two sorted quadruples are min(a_i, b_{3-i}), a
     // bitonic sequence that two exchange stages sort
 #pragma unroll
     for (int o = AREA_LPQ / 2; o >= 1; o >>= 1) {
-        const uint32_t b0 = (uint32_t)__shfl_xor((int)k0, o), b1 = (uint32_t)__shfl_xor((int)k1, o);
-        const uint32_t b2 = (uint32_t)__shfl_xor((int)k2, o), b3 = (uint32_t)__shfl_xor((int)k3, o);
-        k0 = min(k0, b3);
-        k1 = min(k1, b2);
-        k2 = min(k2, b1);
-        k3 = min(k3, b0);
-        cmpx(k0, k2);
-        cmpx(k1, k3);
-        cmpx(k0, k1);
-        cmpx(k2, k3);
+        const unsigned long long b0 = __shfl_xor(k0, o), b1 = __shfl_xor(k1, o), b2 = __shfl_xor(k2, o), b3 = __shfl_xor(k3, o);
+        k0 = b3 < k0 ? b3 : k0;
+        k1 = b2 < k1 ? b2 : k1;
+        k2 = b1 < k2 ? b1 : k2;
+        k3 = b0 < k3 ? b0 : k3;
+        cmpx64(k0, k2);
+        cmpx64(k1, k3);
+        cmpx64(k0, k1);
+        cmpx64(k2, k3);
         cnt += __shfl_xor(cnt, o);
     }
-    if (i < pcap && li < PK) {
-        const uint32_t key = li == 0 ? k0 : li == 1 ? k1 : li == 2 ? k2 : k3;
-        uint32_t word = KEY32_NONE;
-        if (key != KEY32_NONE) word = ((key >> 13) << 16) | (fp[s + (int)(key & 0x1fffu)] & 0xffffu);
-        topk[((long long)f * pcap + i) * PK + li] = word;
-        if (li == 0) nfree[(long long)f * pcap + i] = cnt;
+    if (i < s.nq && li < PK) {
+        const unsigned long long key = li == 0 ? k0 : li == 1 ? k1 : li == 2 ? k2 : k3;
+        topk[((long long)f * s.nq + i) * PK + li] = pkey_word(key);
+        if (li == 0) nfree[(long long)f * s.nq + i] = cnt;
     }
 }
 
@@ -901,8 +922,9 @@ __global__ __launch_bounds__(256) void k_probe_topk(const int32_t* __restrict__ 
 template <int RULE>
 __global__ __launch_bounds__(64) void k_resolve_probe(const OrbProbe* __restrict__ probes, const int32_t* __restrict__ np_arr,
                                                       int pcap, const KpDev* __restrict__ kp2, const int32_t* __restrict__ n2_arr,
-                                                      int cap2, const int32_t* __restrict__ starts,
-                                                      const long long* __restrict__ frame_base, const uint32_t* __restrict__ pairs,
+                                                      int cap2, const int32_t* __restrict__ cell_start,
+                                                      const int32_t* __restrict__ cell_items, GridGeom gg,
+                                                      const uint8_t* __restrict__ desc1, const uint8_t* __restrict__ desc2,
                                                       const uint32_t* __restrict__ topk, const int32_t* __restrict__ nfree,
                                                       const uint8_t* __restrict__ taken, float ratio, int th_dist, int check_ori,
                                                       int32_t* __restrict__ matches_out, int32_t* __restrict__ nmatches_out) {
@@ -919,8 +941,9 @@ __global__ __launch_bounds__(64) void k_resolve_probe(const OrbProbe* __restrict
     }
     if (lane < HISTO_LENGTH + 2) hist[lane] = 0;
     wave_fence();
-    const int32_t* st = starts + (long long)f * (pcap + 1);
-    const uint32_t* fp = pairs + max(frame_base[f], 0LL);
+    const int32_t* cs = cell_start + (long long)f * (GRID_CELLS + 1);
+    const int32_t* its = cell_items + (long long)f * cap2;
+    const uint8_t* d2f = desc2 + (long long)f * cap2 * 32;
     const KpDev* k2f = kp2 + (long long)f * cap2;
     const OrbProbe* pf = probes + (long long)f * pcap;
     const uint4* tkf = (const uint4*)(topk + (long long)f * pcap * PK);
@@ -1007,23 +1030,44 @@ __global__ __launch_bounds__(64) void k_resolve_probe(const OrbProbe* __restrict
                 const uint32_t fmask = (uint32_t)__ballot(is_free) & ((1u << PK) - 1u);
                 const int nfj = __popc(fmask);
                 if ((nfj == 0 || (need2 && nfj < 2)) && !all_listed) {
-                    const int s = st[ip], e = st[ip + 1];
-                    uint32_t k1 = KEY32_NONE, k2 = KEY32_NONE;
-                    for (int bb = s; bb < e; bb += 64) {
-                        const int p = bb + lane;
-                        if (p < e) {
-                            const uint32_t pr = fp[p];
-                            if (owner[pr & 0xffffu] == NONE16) {
-                                const uint32_t key = ((pr >> 16) << 13) | (uint32_t)(p - s);
-                                k2 = min(max(k1, key), k2);
-                                k1 = min(k1, key);
-                            }
-                        }
+                    // the reference's scan: the probe's area once more (the first sixteen lanes enumerate it), every
+                    // feature that is free now
+                    AreaQuery q;
+                    q.active = false;
+                    q.x = q.y = q.r = 0.f;
+                    q.min_level = q.max_level = -1;
+                    uint4 d1a = make_uint4(0, 0, 0, 0), d1b = d1a;
+                    if (lane < AREA_LPQ) {
+                        const OrbProbe& pe = pf[ip];  // valid and finite: it has listed candidates
+                        q.x = pe.u;
+                        q.y = pe.v;
+                        q.r = pe.r;
+                        q.min_level = pe.min_level;
+                        q.max_level = pe.max_level;
+                        q.active = true;
+                        const uint4* d1 = (const uint4*)(desc1 + ((long long)f * pcap + ip) * 32);
+                        d1a = d1[0];
+                        d1b = d1[1];
                     }
-                    uint32_t s1, s2;
-                    wave_two_smallest32(k1, k2, s1, s2);
-                    if (s1 != KEY32_NONE) s1w = ((s1 >> 13) << 16) | (fp[s + (int)(s1 & 0x1fffu)] & 0xffffu);
-                    if (s2 != KEY32_NONE) s2w = ((s2 >> 13) << 16) | (fp[s + (int)(s2 & 0x1fffu)] & 0xffffu);
+                    unsigned long long k1 = PKEY_NONE, k2 = PKEY_NONE;
+                    area_group<true>(gg, k2f, cs, its, q, lane % AREA_LPQ, 0, [&](int i2, int pos) {
+                        if (owner[i2] != NONE16) return;
+                        const uint4* t = (const uint4*)(d2f + (long long)i2 * 32);
+                        const unsigned long long key = pkey(hamming256(t[0], t[1], d1a, d1b), pos, i2);
+                        const unsigned long long hi = key < k1 ? k1 : key;
+                        k2 = hi < k2 ? hi : k2;
+                        k1 = key < k1 ? key : k1;
+                    });
+#pragma unroll
+                    for (int o = 32; o >= 1; o >>= 1) {
+                        const unsigned long long p1 = __shfl_xor(k1, o), p2 = __shfl_xor(k2, o);
+                        const unsigned long long lo = k1 < p1 ? k1 : p1, hi = k1 < p1 ? p1 : k1;
+                        const unsigned long long m2 = k2 < p2 ? k2 : p2;
+                        k2 = hi < m2 ? hi : m2;
+                        k1 = lo;
+                    }
+                    s1w = pkey_word(k1);
+                    s2w = pkey_word(k2);
                 } else if (nfj > 0) {
                     const int first = __ffs(fmask) - 1;
                     s1w = first == 0 ? v0 : first == 1 ? v1 : first == 2 ? v2 : v3;
@@ -1192,9 +1236,6 @@ int orbhip_search_by_projection_device(orbhip_matcher* m, const OrbProbe* d_prob
     s.min_level = s.max_level = -1;
     s.nq = probe_cap;
     HIPCHK(hipEventRecord(m->ev0, m->stream));
-    Candidates c;
-    if ((rc = build_candidates(m, s, d_probe_desc, (const KpDev*)d_kp2, d_desc2, d_cell_start2, d_cell_items2, batch, cap, gg, c)))
-        return rc;
     // per probe: PK candidate words and the count of its free candidates
     const size_t tk_words = (size_t)batch * probe_cap * (PK + 1);
     if (sizeof(uint32_t) * tk_words > m->topk_bytes) {
@@ -1209,19 +1250,18 @@ int orbhip_search_by_projection_device(orbhip_matcher* m, const OrbProbe* d_prob
     uint32_t* d_topk = (uint32_t*)m->d_topk;
     int32_t* d_nfree = (int32_t*)(d_topk + (size_t)batch * probe_cap * PK);
     hipLaunchKernelGGL(k_probe_topk, dim3((unsigned)(((long long)probe_cap * AREA_LPQ + 255) / 256), batch), dim3(256), 0, m->stream,
-                       d_nprobes, probe_cap, cap, c.starts, c.d_base, c.pairs, d_taken, d_topk, d_nfree);
+                       s, (const KpDev*)d_kp2, d_cell_start2, d_cell_items2, cap, gg, d_probe_desc, d_desc2, d_taken, d_topk, d_nfree);
     const size_t lds = sizeof(uint16_t) * (size_t)((cap + 1) & ~1) + sizeof(uint32_t) * (size_t)cap;
 #define LAUNCH_PROBE(R)                                                                                                   \
     hipLaunchKernelGGL(k_resolve_probe<R>, dim3(batch), dim3(64), lds, m->stream, d_probes, d_nprobes, probe_cap,          \
-                       (const KpDev*)d_kp2, d_n2, cap, c.starts, c.d_base, c.pairs, d_topk, d_nfree, d_taken, nnratio,      \
-                       th_dist, check_orientation, d_match_of_feature, d_nmatches)
+                       (const KpDev*)d_kp2, d_n2, cap, d_cell_start2, d_cell_items2, gg, d_probe_desc, d_desc2, d_topk,     \
+                       d_nfree, d_taken, nnratio, th_dist, check_orientation, d_match_of_feature, d_nmatches)
     if (rule == ORBHIP_PROJ_LOCAL_MAP) LAUNCH_PROBE(RULE_LOCAL_MAP);
     else if (rule == ORBHIP_PROJ_RATIO) LAUNCH_PROBE(RULE_RATIO);
     else LAUNCH_PROBE(RULE_BEST);
 #undef LAUNCH_PROBE
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(m->ev1, m->stream));
-    if (m->cand_reserved == 0) HIPCHK(hipStreamSynchronize(m->stream));
     return ORBHIP_OK;
 }
 
