@@ -261,8 +261,8 @@ int orbhip_features_in_area_device(orbhip_matcher* m, const OrbKeypoint* d_kp, c
 #define ORBHIP_SCAN_POPCOUNT 1
 int orbhip_matcher_set_scan_kernel(orbhip_matcher* m, int kind);
 
-/* Asynchronous form of the two windowed matchers below (orbhip_search_for_initialization_device,
- * orbhip_window_search_device; the projection matchers keep no candidate lists and are always asynchronous).  Their
+/* Asynchronous form of orbhip_search_for_initialization_device (orbhip_window_search_device and the projection
+ * matchers keep no candidate lists and are always asynchronous).  Its
  * candidate lists (one 4-byte record per
  * feature that a GetFeaturesInArea call returns) live in a workspace of the handle.  Without a reservation
  * (entries = 0, the default) each call sizes that workspace from a count it reads back from the device, and
@@ -291,7 +291,8 @@ int orbhip_search_for_initialization_device(orbhip_matcher* m, const OrbKeypoint
  * for "F1.mvpMapPoints[i] exists and is not bad"; min_level <= 0 and max_level == INT_MAX switch
  * the level filters off as in the reference.  Output d_matches21 (batch*cap): the F1 index whose
  * map point is assigned to each F2 feature (vpMapPointMatches2[i2] = F1.mvpMapPoints[that]) or -1;
- * d_nmatches (batch).  Blocking unless a reservation is in place, as above. */
+ * d_nmatches (batch).  Asynchronous on the matcher's stream; no candidate lists (the search has the shape of the
+ * projection matchers and runs through the same two kernels, F1's keypoints as the probes). */
 int orbhip_window_search_device(orbhip_matcher* m, const OrbKeypoint* d_kp1, const uint8_t* d_desc1,
                                 const int32_t* d_n1, const uint8_t* d_valid1, const OrbKeypoint* d_kp2,
                                 const uint8_t* d_desc2, const int32_t* d_n2, const int32_t* d_cell_start2,

@@ -767,6 +767,11 @@ int build_candidates(orbhip_matcher* m, const QuerySource& s, const uint8_t* d_d
     return ORBHIP_OK;
 }
 
+enum { RULE_LOCAL_MAP = 0, RULE_RATIO = 1, RULE_BEST = 2 };  // acceptance rules of the two-stage resolution below
+int run_probes(orbhip_matcher* m, const QuerySource& s, int pcap, const uint8_t* d_desc1, const KpDev* d_kp2, const uint8_t* d_desc2,
+               const int32_t* d_n2, const int32_t* d_cs, const int32_t* d_ci, int batch, int cap, const GridGeom& gg,
+               const uint8_t* d_taken, int rule, float ratio, int th_dist, int check_ori, int32_t* d_out, int32_t* d_nmatches);
+
 // Shared body of SearchForInitialization and WindowSearch.
 int run_matcher(orbhip_matcher* m, int mode, const OrbKeypoint* d_kp1, const uint8_t* d_desc1, const int32_t* d_n1,
                 const uint8_t* d_valid1, const OrbKeypoint* d_kp2, const uint8_t* d_desc2, const int32_t* d_n2,
@@ -795,6 +800,17 @@ int run_matcher(orbhip_matcher* m, int mode, const OrbKeypoint* d_kp1, const uin
     s.max_level = max_level;
     s.nq = cap;
     HIPCHK(hipEventRecord(m->ev0, m->stream));
+    if (mode == MODE_WINDOW) {
+        // WindowSearch (src/ORBmatcher.cc:436-523) has the shape of the projection matchers: F1's keypoints in order,
+        // features of F2 that already hold a map point skipped, best / second best with the ratio rule of :487, the
+        // rotation histogram over the matches — its queries are F1's keypoints instead of probe records
+        if ((rc = run_probes(m, s, cap, d_desc1, (const KpDev*)d_kp2, d_desc2, d_n2, d_cell_start2, d_cell_items2, batch, cap, gg,
+                             nullptr, RULE_RATIO, ratio, TH_HIGH, check_ori, d_matches, d_nmatches)))
+            return rc;
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(m->ev1, m->stream));
+        return ORBHIP_OK;
+    }
     Candidates c;
     if ((rc = build_candidates(m, s, d_desc1, (const KpDev*)d_kp2, d_desc2, d_cell_start2, d_cell_items2, batch, cap, gg, c)))
         return rc;
@@ -831,7 +847,6 @@ int run_matcher(orbhip_matcher* m, int mode, const OrbKeypoint* d_kp1, const uin
 //                               both are on one level and best > ratio * second
 //   RULE_RATIO      :585-600   (float)best <= (float)second * ratio && best <= TH_HIGH
 //   RULE_BEST       :1580-1590, :1705-1715, :401-413   best <= th_dist
-enum { RULE_LOCAL_MAP = 0, RULE_RATIO = 1, RULE_BEST = 2 };
 #define TAKEN16 0xfffeu
 #define PK 4
 
@@ -920,8 +935,8 @@ __global__ __launch_bounds__(256) void k_probe_topk(QuerySource s, const KpDev* 
 // the pass: the probes before it are settled, it is resolved by the whole wave, and the rest of the chunk goes again.
 // LDS: owner of every feature (uint16: free, taken on entry, or probe index), the claims of a pass, the histogram.
 template <int RULE>
-__global__ __launch_bounds__(64) void k_resolve_probe(const OrbProbe* __restrict__ probes, const int32_t* __restrict__ np_arr,
-                                                      int pcap, const KpDev* __restrict__ kp2, const int32_t* __restrict__ n2_arr,
+__global__ __launch_bounds__(64) void k_resolve_probe(QuerySource src, int pcap, const KpDev* __restrict__ kp2,
+                                                      const int32_t* __restrict__ n2_arr,
                                                       int cap2, const int32_t* __restrict__ cell_start,
                                                       const int32_t* __restrict__ cell_items, GridGeom gg,
                                                       const uint8_t* __restrict__ desc1, const uint8_t* __restrict__ desc2,
@@ -932,7 +947,7 @@ __global__ __launch_bounds__(64) void k_resolve_probe(const OrbProbe* __restrict
     __shared__ int hist[HISTO_LENGTH + 2];
     __shared__ int nm_sh;
     const int f = blockIdx.x, lane = threadIdx.x;
-    const int np = min(max(np_arr[f], 0), pcap), n2 = min(max(n2_arr[f], 0), cap2);
+    const int np = min(max(src.n1[f], 0), pcap), n2 = min(max(n2_arr[f], 0), cap2);
     uint16_t* owner = lds16;
     uint32_t* claim = (uint32_t*)(lds16 + ((cap2 + 1) & ~1));  // per feature: lowest lane of the current pass that takes it
     for (int i = lane; i < cap2; i += 64) {
@@ -945,7 +960,10 @@ __global__ __launch_bounds__(64) void k_resolve_probe(const OrbProbe* __restrict
     const int32_t* its = cell_items + (long long)f * cap2;
     const uint8_t* d2f = desc2 + (long long)f * cap2 * 32;
     const KpDev* k2f = kp2 + (long long)f * cap2;
-    const OrbProbe* pf = probes + (long long)f * pcap;
+    // the angle a probe brings to the rotation histogram: the probe record's, or that of F1's keypoint (WindowSearch)
+    auto probe_angle = [&](int ip) -> float {
+        return src.mode == MODE_PROBE ? src.probes[(long long)f * pcap + ip].angle : src.kp1[(long long)f * pcap + ip].angle;
+    };
     const uint4* tkf = (const uint4*)(topk + (long long)f * pcap * PK);
     const int32_t* nff = nfree + (long long)f * pcap;
     const bool need2 = RULE != RULE_BEST;
@@ -965,6 +983,20 @@ __global__ __launch_bounds__(64) void k_resolve_probe(const OrbProbe* __restrict
             return (float)bestDist <= __fmul_rn(fBest2, ratio) && bestDist <= TH_HIGH;
         }
         return bestDist <= th_dist;
+    };
+    // Outcome of a probe from its listed candidates alone: 1 accept b1, 0 no match, -1 the whole list is needed.
+    // nf: listed candidates still free (b1 the first, b2 the second); wlast: the last listed word.  With one free
+    // listed candidate and more in the list, every unlisted candidate is at least as far as the last listed one, and
+    // the rules are monotone in the second-best distance: if the best passes against that bound it passes against
+    // the true second best, whatever its level.
+    auto decide = [&](uint32_t b1, uint32_t b2, int nf, bool listed_all, uint32_t wlast) -> int {
+        if (nf == 0) return listed_all ? 0 : -1;
+        if (!need2 || nf >= 2 || listed_all) return accepts(b1, b2) ? 1 : 0;
+        const int bestDist = (int)(b1 >> 16);
+        if (bestDist > TH_HIGH) return 0;
+        const float bound = (float)(int)(wlast >> 16);
+        const bool passes = RULE == RULE_RATIO ? (float)bestDist <= __fmul_rn(bound, ratio) : !((float)bestDist > __fmul_rn(ratio, bound));
+        return passes ? 1 : -1;
     };
     int nmatches = 0;
     for (int c0 = 0; c0 < np; c0 += 64) {
@@ -994,9 +1026,10 @@ __global__ __launch_bounds__(64) void k_resolve_probe(const OrbProbe* __restrict
                     }
                 }
             }
-            // too few of the listed candidates left and more in the list: this probe needs the full scan
-            bool alone = live && (nf == 0 || (need2 && nf < 2)) && !listed_all;
-            const bool take = live && !alone && b1 != KEY32_NONE && accepts(b1, b2);
+            // too few of the listed candidates left to tell: this probe needs the full scan
+            const int verdict = live ? decide(b1, b2, nf, listed_all, w[PK - 1]) : 0;
+            bool alone = verdict < 0;
+            const bool take = verdict > 0;
             // an earlier probe of the chunk that takes one of this probe's listed candidates changes its outcome:
             // every taker claims its feature with its lane number, the lowest lane wins the claim
             if (take) atomicMin(&claim[b1 & 0xffffu], (uint32_t)lane);
@@ -1029,7 +1062,19 @@ __global__ __launch_bounds__(64) void k_resolve_probe(const OrbProbe* __restrict
                 const bool is_free = lane < PK && word != KEY32_NONE && owner[word & 0xffffu] == NONE16;
                 const uint32_t fmask = (uint32_t)__ballot(is_free) & ((1u << PK) - 1u);
                 const int nfj = __popc(fmask);
-                if ((nfj == 0 || (need2 && nfj < 2)) && !all_listed) {
+                int verdict = -1;
+                if (nfj > 0) {
+                    const int first = __ffs(fmask) - 1;
+                    s1w = first == 0 ? v0 : first == 1 ? v1 : first == 2 ? v2 : v3;
+                    const uint32_t rest = fmask & (fmask - 1u);
+                    if (rest) {
+                        const int second = __ffs(rest) - 1;
+                        s2w = second == 1 ? v1 : second == 2 ? v2 : v3;
+                    }
+                }
+                verdict = decide(s1w, s2w, nfj, all_listed, v3);
+                if (verdict < 0) {
+                    s1w = s2w = KEY32_NONE;
                     // the reference's scan: the probe's area once more (the first sixteen lanes enumerate it), every
                     // feature that is free now
                     AreaQuery q;
@@ -1038,13 +1083,7 @@ __global__ __launch_bounds__(64) void k_resolve_probe(const OrbProbe* __restrict
                     q.min_level = q.max_level = -1;
                     uint4 d1a = make_uint4(0, 0, 0, 0), d1b = d1a;
                     if (lane < AREA_LPQ) {
-                        const OrbProbe& pe = pf[ip];  // valid and finite: it has listed candidates
-                        q.x = pe.u;
-                        q.y = pe.v;
-                        q.r = pe.r;
-                        q.min_level = pe.min_level;
-                        q.max_level = pe.max_level;
-                        q.active = true;
+                        q = make_query(src, f, ip);  // active: it has listed candidates
                         const uint4* d1 = (const uint4*)(desc1 + ((long long)f * pcap + ip) * 32);
                         d1a = d1[0];
                         d1b = d1[1];
@@ -1068,16 +1107,9 @@ __global__ __launch_bounds__(64) void k_resolve_probe(const OrbProbe* __restrict
                     }
                     s1w = pkey_word(k1);
                     s2w = pkey_word(k2);
-                } else if (nfj > 0) {
-                    const int first = __ffs(fmask) - 1;
-                    s1w = first == 0 ? v0 : first == 1 ? v1 : first == 2 ? v2 : v3;
-                    const uint32_t rest = fmask & (fmask - 1u);
-                    if (rest) {
-                        const int second = __ffs(rest) - 1;
-                        s2w = second == 1 ? v1 : second == 2 ? v2 : v3;
-                    }
+                    verdict = s1w != KEY32_NONE && accepts(s1w, s2w) ? 1 : 0;
                 }
-                if (s1w != KEY32_NONE && accepts(s1w, s2w)) {
+                if (verdict > 0) {
                     if (lane == 0) owner[s1w & 0xffffu] = (uint16_t)ip;
                     nmatches++;
                 }
@@ -1091,12 +1123,12 @@ __global__ __launch_bounds__(64) void k_resolve_probe(const OrbProbe* __restrict
     wave_fence();
     if (check_ori) {  // :1592-1602 and :1608-1628
         for (int i2 = lane; i2 < n2; i2 += 64)
-            if (owner[i2] < TAKEN16) atomicAdd(&hist[rot_bin(pf[owner[i2]].angle, k2f[i2].angle)], 1);
+            if (owner[i2] < TAKEN16) atomicAdd(&hist[rot_bin(probe_angle(owner[i2]), k2f[i2].angle)], 1);
         wave_fence();
         const uint32_t keep = three_maxima_mask(hist);
         int removed = 0;
         for (int i2 = lane; i2 < n2; i2 += 64)
-            if (owner[i2] < TAKEN16 && !((keep >> rot_bin(pf[owner[i2]].angle, k2f[i2].angle)) & 1u)) {
+            if (owner[i2] < TAKEN16 && !((keep >> rot_bin(probe_angle(owner[i2]), k2f[i2].angle)) & 1u)) {
                 owner[i2] = NONE16;
                 removed++;
             }
@@ -1110,6 +1142,38 @@ __global__ __launch_bounds__(64) void k_resolve_probe(const OrbProbe* __restrict
         const uint32_t v = i2 < n2 ? owner[i2] : NONE16;
         mo[i2] = v < TAKEN16 ? (int32_t)v : -1;
     }
+}
+
+// The two stages for `batch` frames: queries from `s` (probe records, or F1's keypoints for WindowSearch), pcap of them
+// per frame with their descriptors at d_desc1.
+int run_probes(orbhip_matcher* m, const QuerySource& s, int pcap, const uint8_t* d_desc1, const KpDev* d_kp2, const uint8_t* d_desc2,
+               const int32_t* d_n2, const int32_t* d_cs, const int32_t* d_ci, int batch, int cap, const GridGeom& gg,
+               const uint8_t* d_taken, int rule, float ratio, int th_dist, int check_ori, int32_t* d_out, int32_t* d_nmatches) {
+    // per probe: PK candidate words and the count of its free candidates
+    const size_t tk_words = (size_t)batch * pcap * (PK + 1);
+    if (sizeof(uint32_t) * tk_words > m->topk_bytes) {
+        HIPCHK(hipStreamSynchronize(m->stream));
+        if (m->d_topk) (void)hipFree(m->d_topk);
+        m->d_topk = nullptr;
+        m->topk_bytes = 0;
+        if (hipMalloc(&m->d_topk, sizeof(uint32_t) * tk_words) != hipSuccess)
+            return orb_fail(ORBHIP_ENOMEM, "hipMalloc of %zu bytes failed", sizeof(uint32_t) * tk_words);
+        m->topk_bytes = sizeof(uint32_t) * tk_words;
+    }
+    uint32_t* d_topk = (uint32_t*)m->d_topk;
+    int32_t* d_nfree = (int32_t*)(d_topk + (size_t)batch * pcap * PK);
+    hipLaunchKernelGGL(k_probe_topk, dim3((unsigned)(((long long)pcap * AREA_LPQ + 255) / 256), batch), dim3(256), 0, m->stream,
+                       s, (const KpDev*)d_kp2, d_cs, d_ci, cap, gg, d_desc1, d_desc2, d_taken, d_topk, d_nfree);
+    const size_t lds = sizeof(uint16_t) * (size_t)((cap + 1) & ~1) + sizeof(uint32_t) * (size_t)cap;
+#define LAUNCH_PROBE(R)                                                                                                   \
+    hipLaunchKernelGGL(k_resolve_probe<R>, dim3(batch), dim3(64), lds, m->stream, s, pcap, (const KpDev*)d_kp2, d_n2,  \
+                       cap, d_cs, d_ci, gg, d_desc1, d_desc2, d_topk, d_nfree, d_taken, ratio,     \
+                       th_dist, check_ori, d_out, d_nmatches)
+    if (rule == RULE_LOCAL_MAP) LAUNCH_PROBE(RULE_LOCAL_MAP);
+    else if (rule == RULE_RATIO) LAUNCH_PROBE(RULE_RATIO);
+    else LAUNCH_PROBE(RULE_BEST);
+#undef LAUNCH_PROBE
+    return ORBHIP_OK;
 }
 
 }  // namespace
@@ -1236,30 +1300,10 @@ int orbhip_search_by_projection_device(orbhip_matcher* m, const OrbProbe* d_prob
     s.min_level = s.max_level = -1;
     s.nq = probe_cap;
     HIPCHK(hipEventRecord(m->ev0, m->stream));
-    // per probe: PK candidate words and the count of its free candidates
-    const size_t tk_words = (size_t)batch * probe_cap * (PK + 1);
-    if (sizeof(uint32_t) * tk_words > m->topk_bytes) {
-        HIPCHK(hipStreamSynchronize(m->stream));
-        if (m->d_topk) (void)hipFree(m->d_topk);
-        m->d_topk = nullptr;
-        m->topk_bytes = 0;
-        if (hipMalloc(&m->d_topk, sizeof(uint32_t) * tk_words) != hipSuccess)
-            return orb_fail(ORBHIP_ENOMEM, "hipMalloc of %zu bytes failed", sizeof(uint32_t) * tk_words);
-        m->topk_bytes = sizeof(uint32_t) * tk_words;
-    }
-    uint32_t* d_topk = (uint32_t*)m->d_topk;
-    int32_t* d_nfree = (int32_t*)(d_topk + (size_t)batch * probe_cap * PK);
-    hipLaunchKernelGGL(k_probe_topk, dim3((unsigned)(((long long)probe_cap * AREA_LPQ + 255) / 256), batch), dim3(256), 0, m->stream,
-                       s, (const KpDev*)d_kp2, d_cell_start2, d_cell_items2, cap, gg, d_probe_desc, d_desc2, d_taken, d_topk, d_nfree);
-    const size_t lds = sizeof(uint16_t) * (size_t)((cap + 1) & ~1) + sizeof(uint32_t) * (size_t)cap;
-#define LAUNCH_PROBE(R)                                                                                                   \
-    hipLaunchKernelGGL(k_resolve_probe<R>, dim3(batch), dim3(64), lds, m->stream, d_probes, d_nprobes, probe_cap,          \
-                       (const KpDev*)d_kp2, d_n2, cap, d_cell_start2, d_cell_items2, gg, d_probe_desc, d_desc2, d_topk,     \
-                       d_nfree, d_taken, nnratio, th_dist, check_orientation, d_match_of_feature, d_nmatches)
-    if (rule == ORBHIP_PROJ_LOCAL_MAP) LAUNCH_PROBE(RULE_LOCAL_MAP);
-    else if (rule == ORBHIP_PROJ_RATIO) LAUNCH_PROBE(RULE_RATIO);
-    else LAUNCH_PROBE(RULE_BEST);
-#undef LAUNCH_PROBE
+    if ((rc = run_probes(m, s, probe_cap, d_probe_desc, (const KpDev*)d_kp2, d_desc2, d_n2, d_cell_start2, d_cell_items2, batch, cap,
+                         gg, d_taken, rule == ORBHIP_PROJ_LOCAL_MAP ? RULE_LOCAL_MAP : rule == ORBHIP_PROJ_RATIO ? RULE_RATIO : RULE_BEST,
+                         nnratio, th_dist, check_orientation, d_match_of_feature, d_nmatches)))
+        return rc;
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(m->ev1, m->stream));
     return ORBHIP_OK;

@@ -64,19 +64,31 @@ def test_reservation_too_small_fails_at_synchronize(orb, synth):
     m = orb.ORBmatcher(0.9, True)
     m.reserve_candidates(64)
     F1 = orb.FrameBatch.from_images(ext, m, img)
-    valid = torch.ones((b, nf), dtype=torch.uint8, device="cuda")
-    nm, m21 = m.WindowSearch(F1, F1, 40, valid, 0)
+    # SearchForInitialization keeps candidate lists (WindowSearch and the projection matchers store none)
+    prev = F1.kp.view(torch.float32).view(b, F1.cap, 7)[:, :, 0:2].contiguous()
+    nm, m12 = m.SearchForInitialization(F1, F1, prev.clone(), 40)
     with pytest.raises(orb.OrbhipError) as e:
         m.synchronize()
     assert "reservation" in str(e.value) and e.value.code == orb._lib.ECAP
     torch.cuda.synchronize()
-    assert int(nm.sum()) == 0 and bool((m21 == -1).all())
+    assert int(nm.sum()) == 0 and bool((m12 == -1).all())
     # the flag is cleared by the failed synchronisation; with room the same call works, and 0 returns to blocking
     m.reserve_candidates(4 << 20)
-    nm, m21 = m.WindowSearch(F1, F1, 40, valid, 0)
+    nm, m12 = m.SearchForInitialization(F1, F1, prev.clone(), 40)
     m.synchronize()
     torch.cuda.synchronize()
     assert int(nm.sum()) > 100
     m.reserve_candidates(0)
-    nm2, m21b = m.WindowSearch(F1, F1, 40, valid, 0)
-    assert torch.equal(m21, m21b)
+    nm2, m12b = m.SearchForInitialization(F1, F1, prev.clone(), 40)
+    assert torch.equal(m12, m12b)
+    # the projection matchers are indifferent to the reservation
+    m.reserve_candidates(64)
+    pr = torch.zeros((b, F1.cap, 8), dtype=torch.float32, device="cuda")
+    pr[:, :, 0:2] = prev
+    pr[:, :, 2] = 20.0
+    pr.view(torch.int32)[:, :, 3:5] = -1
+    pr.view(torch.int32)[:, :, 6] = 1
+    nmp, _ = m.SearchByProjection(F1, pr.view(torch.uint8).view(b, F1.cap, 32), F1.desc, F1.n, orb.ORBmatcher.PROJ_BEST, th_dist=100)
+    m.synchronize()
+    torch.cuda.synchronize()
+    assert int(nmp.sum()) > 100
