@@ -501,11 +501,11 @@ __device__ inline uint32_t three_maxima_mask(const int* hist) {
     return mask;
 }
 
-// mode MODE_SEARCH_INIT or MODE_WINDOW.  LDS: four uint16 arrays of cap entries, the candidate
-// run buffer (RB_CAP entries, at byte offset 8 * cap) and the histogram.
-template <int MODE>
-__global__ __launch_bounds__(64) void k_resolve(const KpDev* __restrict__ kp1, const int32_t* __restrict__ n1_arr,
-                                                const KpDev* __restrict__ kp2, const int32_t* __restrict__ n2_arr, int cap,
+// Sequential part of SearchForInitialization (src/ORBmatcher.cc:609-724): one wave per frame pair walks F1's
+// keypoints over the candidate lists.  LDS: four uint16 arrays of cap entries, the candidate run buffer
+// (RB_CAP entries, at byte offset 8 * cap) and the histogram.
+__global__ __launch_bounds__(64) void k_resolve_init(const KpDev* __restrict__ kp1, const int32_t* __restrict__ n1_arr,
+                                                     const KpDev* __restrict__ kp2, const int32_t* __restrict__ n2_arr, int cap,
                                                 const int32_t* __restrict__ starts, const long long* __restrict__ frame_base,
                                                 const uint32_t* __restrict__ pairs, float ratio, int check_ori,
                                                 float* __restrict__ prev, int32_t* __restrict__ matches_out,
@@ -515,10 +515,10 @@ __global__ __launch_bounds__(64) void k_resolve(const KpDev* __restrict__ kp1, c
     __shared__ int nm_sh;
     const int f = blockIdx.x, lane = threadIdx.x;
     const int n1 = min(max(n1_arr[f], 0), cap), n2 = min(max(n2_arr[f], 0), cap);
-    uint16_t* matchedDist = lds16;      // vMatchedDistance (SEARCH_INIT); NONE16 = INT_MAX
+    uint16_t* matchedDist = lds16;      // vMatchedDistance; NONE16 = INT_MAX
     uint16_t* m21 = lds16 + cap;        // vnMatches21
-    uint16_t* m12 = lds16 + 2 * cap;    // vnMatches12 (SEARCH_INIT)
-    uint16_t* partner = lds16 + 3 * cap;  // SEARCH_INIT: F2 index i1 was pushed to the histogram with
+    uint16_t* m12 = lds16 + 2 * cap;    // vnMatches12
+    uint16_t* partner = lds16 + 3 * cap;  // F2 index i1 was pushed to the histogram with
     for (int i = lane; i < cap; i += 64) {
         matchedDist[i] = NONE16;
         m21[i] = NONE16;
@@ -563,10 +563,7 @@ __global__ __launch_bounds__(64) void k_resolve(const KpDev* __restrict__ kp1, c
                     if (p < e) {
                         const uint32_t pr = buffered ? cbuf[p - S] : fp[p];
                         const uint32_t i2 = pr & 0xffffu, dist = pr >> 16;
-                        bool skip;
-                        if (MODE == MODE_SEARCH_INIT) skip = (uint32_t)matchedDist[i2] <= dist;  // :648
-                        else skip = m21[i2] != NONE16;                                            // :469
-                        if (!skip) {
+                        if ((uint32_t)matchedDist[i2] > dist) {  // :648
                             const uint32_t key = (dist << 13) | (uint32_t)(p - s);
                             k2 = min(max(k1, key), k2);
                             k1 = min(k1, key);
@@ -580,26 +577,16 @@ __global__ __launch_bounds__(64) void k_resolve(const KpDev* __restrict__ kp1, c
                 const int bpos = s + (int)(b1 & 0x1fffu);
                 const int bestIdx2 = (int)((buffered ? cbuf[bpos - S] : fp[bpos]) & 0xffffu);
                 const float fBest2 = b2 == KEY32_NONE ? (float)INT_MAX : (float)(int)(b2 >> 13);
-                bool accept;
-                if (MODE == MODE_SEARCH_INIT)
-                    accept = bestDist <= TH_LOW && (float)bestDist < __fmul_rn(fBest2, ratio);  // :663-665
-                else
-                    accept = (float)bestDist <= __fmul_rn(fBest2, ratio) && bestDist <= TH_HIGH;  // :487
-                if (accept) {
-                    if (MODE == MODE_SEARCH_INIT) {
-                        const uint32_t old = m21[bestIdx2];
-                        if (old != NONE16) nmatches--;
-                        wave_fence();
-                        if (lane == 0) {
-                            if (old != NONE16) m12[old] = NONE16;
-                            m12[i1] = (uint16_t)bestIdx2;
-                            m21[bestIdx2] = (uint16_t)i1;
-                            matchedDist[bestIdx2] = (uint16_t)bestDist;
-                            partner[i1] = (uint16_t)bestIdx2;
-                        }
-                    } else {
-                        wave_fence();
-                        if (lane == 0) m21[bestIdx2] = (uint16_t)i1;
+                if (bestDist <= TH_LOW && (float)bestDist < __fmul_rn(fBest2, ratio)) {  // :663-665
+                    const uint32_t old = m21[bestIdx2];
+                    if (old != NONE16) nmatches--;
+                    wave_fence();
+                    if (lane == 0) {
+                        if (old != NONE16) m12[old] = NONE16;
+                        m12[i1] = (uint16_t)bestIdx2;
+                        m21[bestIdx2] = (uint16_t)i1;
+                        matchedDist[bestIdx2] = (uint16_t)bestDist;
+                        partner[i1] = (uint16_t)bestIdx2;
                     }
                     nmatches++;
                     wave_fence();
@@ -617,49 +604,29 @@ __global__ __launch_bounds__(64) void k_resolve(const KpDev* __restrict__ kp1, c
     if (lane == 0) nm_sh = 0;
     wave_fence();
     if (check_ori) {
-        if (MODE == MODE_SEARCH_INIT) {
-            for (int i1 = lane; i1 < n1; i1 += 64)
-                if (partner[i1] != NONE16) atomicAdd(&hist[rot_bin(k1f[i1].angle, k2f[partner[i1]].angle)], 1);
-        } else {
-            for (int i2 = lane; i2 < n2; i2 += 64)
-                if (m21[i2] != NONE16) atomicAdd(&hist[rot_bin(k1f[m21[i2]].angle, k2f[i2].angle)], 1);
-        }
+        for (int i1 = lane; i1 < n1; i1 += 64)
+            if (partner[i1] != NONE16) atomicAdd(&hist[rot_bin(k1f[i1].angle, k2f[partner[i1]].angle)], 1);
         wave_fence();
         const uint32_t keep = three_maxima_mask(hist);
         int removed = 0;
-        if (MODE == MODE_SEARCH_INIT) {
-            for (int i1 = lane; i1 < n1; i1 += 64)
-                if (partner[i1] != NONE16 && !((keep >> rot_bin(k1f[i1].angle, k2f[partner[i1]].angle)) & 1u) &&
-                    m12[i1] != NONE16) {
-                    m12[i1] = NONE16;
-                    removed++;
-                }
-        } else {
-            for (int i2 = lane; i2 < n2; i2 += 64)
-                if (m21[i2] != NONE16 && !((keep >> rot_bin(k1f[m21[i2]].angle, k2f[i2].angle)) & 1u)) {
-                    m21[i2] = NONE16;
-                    removed++;
-                }
-        }
+        for (int i1 = lane; i1 < n1; i1 += 64)
+            if (partner[i1] != NONE16 && !((keep >> rot_bin(k1f[i1].angle, k2f[partner[i1]].angle)) & 1u) &&
+                m12[i1] != NONE16) {
+                m12[i1] = NONE16;
+                removed++;
+            }
         if (removed) atomicAdd(&nm_sh, removed);
         wave_fence();
     }
     nmatches -= nm_sh;
     if (lane == 0) nmatches_out[f] = nmatches;
     int32_t* mo = matches_out + (long long)f * cap;
-    if (MODE == MODE_SEARCH_INIT) {
-        for (int i1 = lane; i1 < cap; i1 += 64) {
-            const uint32_t v = i1 < n1 ? m12[i1] : NONE16;
-            mo[i1] = v == NONE16 ? -1 : (int32_t)v;
-            if (v != NONE16) {  // "Update prev matched", :719-721
-                prev[((long long)f * cap + i1) * 2] = k2f[v].x;
-                prev[((long long)f * cap + i1) * 2 + 1] = k2f[v].y;
-            }
-        }
-    } else {
-        for (int i2 = lane; i2 < cap; i2 += 64) {
-            const uint32_t v = i2 < n2 ? m21[i2] : NONE16;
-            mo[i2] = v == NONE16 ? -1 : (int32_t)v;
+    for (int i1 = lane; i1 < cap; i1 += 64) {
+        const uint32_t v = i1 < n1 ? m12[i1] : NONE16;
+        mo[i1] = v == NONE16 ? -1 : (int32_t)v;
+        if (v != NONE16) {  // "Update prev matched", :719-721
+            prev[((long long)f * cap + i1) * 2] = k2f[v].x;
+            prev[((long long)f * cap + i1) * 2 + 1] = k2f[v].y;
         }
     }
 }
@@ -815,17 +782,9 @@ int run_matcher(orbhip_matcher* m, int mode, const OrbKeypoint* d_kp1, const uin
     if ((rc = build_candidates(m, s, d_desc1, (const KpDev*)d_kp2, d_desc2, d_cell_start2, d_cell_items2, batch, cap, gg, c)))
         return rc;
     const size_t lds = sizeof(uint16_t) * 4 * (size_t)cap + sizeof(uint32_t) * RB_CAP;
-    if (mode == MODE_SEARCH_INIT) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_resolve<MODE_SEARCH_INIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_resolve<MODE_SEARCH_INIT>, dim3(batch), dim3(64), lds, m->stream, (const KpDev*)d_kp1, d_n1,
-                           (const KpDev*)d_kp2, d_n2, cap, c.starts, c.d_base, c.pairs, ratio, check_ori, d_prev, d_matches,
-                           d_nmatches);
-    } else {
-        HIPCHK(hipFuncSetAttribute((const void*)k_resolve<MODE_WINDOW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_resolve<MODE_WINDOW>, dim3(batch), dim3(64), lds, m->stream, (const KpDev*)d_kp1, d_n1,
-                           (const KpDev*)d_kp2, d_n2, cap, c.starts, c.d_base, c.pairs, ratio, check_ori, d_prev, d_matches,
-                           d_nmatches);
-    }
+    HIPCHK(hipFuncSetAttribute((const void*)k_resolve_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_resolve_init, dim3(batch), dim3(64), lds, m->stream, (const KpDev*)d_kp1, d_n1, (const KpDev*)d_kp2,
+                       d_n2, cap, c.starts, c.d_base, c.pairs, ratio, check_ori, d_prev, d_matches, d_nmatches);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(m->ev1, m->stream));
     if (m->cand_reserved == 0) HIPCHK(hipStreamSynchronize(m->stream));

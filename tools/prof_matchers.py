@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The matcher legs of bench.py alone, for rocprofv3 passes over the matcher kernels (k_knn2, k_knn2_fold,
-k_knn2_merge, k_area_*, k_resolve*, k_frame_grid, k_bow_*):
+k_knn2_merge, k_area_*, k_resolve_init, k_probe_topk, k_resolve_probe, k_frame_grid, k_bow_*):
 
   rocprofv3 --kernel-trace --stats -d <dir> -- python3 tools/prof_matchers.py [knn|windowed|bow ...]
 """
