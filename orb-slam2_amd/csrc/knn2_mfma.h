@@ -27,6 +27,15 @@
 // query's two smallest if its distance is below the query's second-best distance so far: one wave vote per tile
 // on the minima of the lanes' results, then one vote per result, skips the keyed folds (which are exact whatever
 // the votes let through).
+//
+// The first tiles of a chunk do not vote.  While a scan is young nearly every tile holds a result that enters some
+// query's two smallest (a query's second-best improves about 2 / j times in tile j, and a wave carries 64 queries), so
+// the votes and scalar branches are paid in every tile and skip nothing.  Those tiles (KMM_SORT_TILES_DEFAULT of
+// them) run a branch-free two-slot sorted insertion on float keys instead, three full-rate instructions per result:
+// the key is d - popcount(q) + row / 2^10, and the row fraction is fed to the tile's first matrix instruction as its
+// accumulator input, so the instruction's result is the key.  The two smallest keys per lane are the same two rows
+// the keyed folds would keep (keys are distinct and order like (distance, row)); they are converted to the integer
+// keys once, where the vote path takes over.
 #pragma once
 #include <type_traits>
 
@@ -35,6 +44,10 @@
 #define KMM_THR_NONE 0x400  // above every d - popcount(q)
 #define KMM_BIAS 256        // keys carry d - popcount(q) + 256 until the end
 #define KMM_TILE 32         // train rows per tile
+#define KMM_FKEY_BITS 10    // row bits of the float keys of the insertion phase (the fraction of the key)
+#define KMM_FKEY_SCALE (1 << KMM_FKEY_BITS)
+#define KMM_SORT_TILES_MAX (KMM_FKEY_SCALE / KMM_TILE)  // rows of the insertion phase stay below 2^10
+#define KMM_SORT_TILES_DEFAULT 24
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -49,7 +62,7 @@ __global__ __launch_bounds__(256) void k_knn2_mm(const uint32_t* __restrict__ q,
                                                   const uint32_t* __restrict__ t, int nt, long long t_pair_words,
                                                   int chunk_rows, int nchunks, int idx_base, uint2* __restrict__ part,
                                                   int32_t* __restrict__ o_idx, int32_t* __restrict__ o_d1,
-                                                  int32_t* __restrict__ o_d2) {
+                                                  int32_t* __restrict__ o_d2, int sort_tiles) {
     const int pair = blockIdx.z, chunk = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, col = lane & 31;
@@ -95,8 +108,17 @@ __global__ __launch_bounds__(256) void k_knn2_mm(const uint32_t* __restrict__ q,
         v.w[3] = p[3];
         return v;
     };
-    auto tile = [&](const int r0, const Row4& cur, auto tail_tag) {
+    // Float keys of the insertion phase: d - popcount(q) + (chunk-relative row) / 2^10.  The row fraction enters as
+    // the accumulator input of a tile's first matrix instruction, so the instruction's result IS the key: sums of
+    // integers of magnitude <= 256 and a 10-bit fraction are exact in fp32 (19 significant bits).  ckey[i] is the
+    // fraction of result register i for the current tile.
+    float fk1[2] = {__builtin_inff(), __builtin_inff()}, fk2[2] = {__builtin_inff(), __builtin_inff()};
+    f32x16 ckey;
+#pragma unroll
+    for (int i = 0; i < 16; i++) ckey[i] = (float)(4 * h + (i & 3) + 8 * (i >> 2)) * (1.f / KMM_FKEY_SCALE);
+    auto tile = [&](const int r0, const Row4& cur, auto tail_tag, auto sort_tag) {
         constexpr bool TAIL = decltype(tail_tag)::value;
+        constexpr bool SORT = decltype(sort_tag)::value;
         // acc[qt][reg] = d - popcount(q) for row r0 + (reg & 3) + 8 (reg >> 2) + 4 h
         f32x16 acc[2];
 #pragma unroll
@@ -108,13 +130,29 @@ __global__ __launch_bounds__(256) void k_knn2_mm(const uint32_t* __restrict__ q,
 #endif
 #pragma unroll
             for (int qt = 0; qt < 2; qt++) {
-                if (ks == 0)
+                if (ks == 0 && SORT)
+                    acc[qt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[qt][0], ckey, 4, 4, 0, 0, 0, 0);
+                else if (ks == 0)
                     acc[qt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
                         a, bq[qt][0], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 4, 4, 0, 0,
                         0, 0);
                 else
                     acc[qt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[qt][ks], acc[qt], 4, 4, 0, 0, 0, 0);
             }
+        }
+        if constexpr (SORT) {
+            // every result goes through a two-slot sorted insertion: three full-rate instructions, no vote, no branch
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+#pragma unroll
+                for (int qt = 0; qt < 2; qt++) {
+                    const float k = acc[qt][i];
+                    fk2[qt] = __builtin_fminf(fk2[qt], __builtin_fmaxf(fk1[qt], k));
+                    fk1[qt] = __builtin_fminf(fk1[qt], k);
+                }
+            }
+            ckey += (float)KMM_TILE / KMM_FKEY_SCALE;
+            return;
         }
         float below[2];
 #pragma unroll
@@ -156,13 +194,36 @@ __global__ __launch_bounds__(256) void k_knn2_mm(const uint32_t* __restrict__ q,
     };
     if (rows > 0) {
         const int nfull = rows / KMM_TILE;
+        const int nsort = min(nfull, sort_tiles);
         Row4 cur = load_row(col);
-        for (int ti = 0; ti < nfull; ti++) {
+        int ti = 0;
+        for (; ti < nsort; ti++) {
             const Row4 nxt = load_row((ti + 1) * KMM_TILE + col);
-            tile(ti * KMM_TILE, cur, std::false_type{});
+            tile(ti * KMM_TILE, cur, std::false_type{}, std::true_type{});
             cur = nxt;
         }
-        if (nfull * KMM_TILE < rows) tile(nfull * KMM_TILE, cur, std::true_type{});
+        if (nsort > 0) {
+            // float keys -> the integer keys of the vote phase, and the query's threshold over both of its lanes
+#pragma unroll
+            for (int qt = 0; qt < 2; qt++) {
+                // (key + 256) * 2^10 is an integer below 2^20: biased distance above the row
+                const uint32_t u1 = (uint32_t)((fk1[qt] + (float)KMM_BIAS) * (float)KMM_FKEY_SCALE);
+                const uint32_t u2 = (uint32_t)((fk2[qt] + (float)KMM_BIAS) * (float)KMM_FKEY_SCALE);
+                best[qt] = fk1[qt] == __builtin_inff() ? KNN_NONE
+                                                        : ((u1 >> KMM_FKEY_BITS) << KNN_IDX_BITS) + (u1 & (KMM_FKEY_SCALE - 1));
+                best2[qt] = fk2[qt] == __builtin_inff() ? KNN_NONE
+                                                         : ((u2 >> KMM_FKEY_BITS) << KNN_IDX_BITS) + (u2 & (KMM_FKEY_SCALE - 1));
+                const uint32_t ob = (uint32_t)__shfl_xor((int)best[qt], 32), ob2 = (uint32_t)__shfl_xor((int)best2[qt], 32);
+                const uint32_t s2 = min(max(best[qt], ob), min(best2[qt], ob2));
+                thr[qt] = s2 == KNN_NONE ? (float)KMM_THR_NONE : (float)((int)(s2 >> KNN_IDX_BITS) - KMM_BIAS);
+            }
+        }
+        for (; ti < nfull; ti++) {
+            const Row4 nxt = load_row((ti + 1) * KMM_TILE + col);
+            tile(ti * KMM_TILE, cur, std::false_type{}, std::false_type{});
+            cur = nxt;
+        }
+        if (nfull * KMM_TILE < rows) tile(nfull * KMM_TILE, cur, std::true_type{}, std::false_type{});
     }
 
 #ifdef KMM_EXP_CLOCK

@@ -315,10 +315,16 @@ static int knn2_launch(orbhip_matcher* m, const KnnPlan& plan, const uint8_t* d_
                        const uint8_t* d_t, int nt, ptrdiff_t t_pair_stride, int npairs, int idx_base, uint2* d_part,
                        int32_t* d_idx, int32_t* d_d1, int32_t* d_d2) {
     HIPCHK(hipEventRecord(m->ev0, m->stream));
+    // tiles of a chunk that go through the branch-free insertion before the vote path takes over
+    static const int sort_tiles = [] {
+        const char* e = getenv("ORBHIP_KNN_SORT_TILES");  // tuning experiments only
+        const int v = e ? atoi(e) : KMM_SORT_TILES_DEFAULT;
+        return std::max(0, std::min(v, (int)KMM_SORT_TILES_MAX));
+    }();
     if (m->scan_kernel == ORBHIP_SCAN_MATRIX)
         hipLaunchKernelGGL(k_knn2_mm, dim3(plan.qblocks, plan.nchunks, npairs), dim3(256), 0, m->stream, (const uint32_t*)d_q,
                            nq, (long long)(q_pair_stride / 4), (const uint32_t*)d_t, nt, (long long)(t_pair_stride / 4),
-                           plan.chunk_rows, plan.nchunks, idx_base, d_part, d_idx, d_d1, d_d2);
+                           plan.chunk_rows, plan.nchunks, idx_base, d_part, d_idx, d_d1, d_d2, sort_tiles);
     else
         hipLaunchKernelGGL(k_knn2, dim3(plan.qblocks, plan.nchunks, npairs), dim3(256), 0, m->stream, (const uint32_t*)d_q, nq,
                            (long long)(q_pair_stride / 4), (const uint32_t*)d_t, nt, (long long)(t_pair_stride / 4),

@@ -76,7 +76,7 @@ int main(int argc, char** argv) {
     for (int r = 0; r < 8; r++) {
         hipEventRecord(e0);
         hipLaunchKernelGGL(k_knn2_mm, dim3(qblocks, nchunks, 1), dim3(256), 0, 0, q, nq, 0LL, t, nt, 0LL, chunk_rows, nchunks, 0, part,
-                           o, o + nq, o + 2 * nq);
+                           o, o + nq, o + 2 * nq, KMM_SORT_TILES_DEFAULT);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
