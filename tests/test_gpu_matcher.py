@@ -129,6 +129,43 @@ def test_knn2_extreme_popcounts(orb, orbref, scan):
 
 
 @pytest.mark.parametrize("scan", SCANS)
+@pytest.mark.parametrize("nt", [736, 767, 768, 769, 799, 800, 1023, 1024, 1025, 2000])
+def test_knn2_insertion_phase_boundary(orb, orbref, nt, scan):
+    """The matrix kernel keeps the two smallest of a chunk's first 768 rows (24 tiles) by sorted insertion on float
+    keys (distance - popcount(query) + row / 1024) and the rest by votes and integer keys: equal rows on both sides
+    of the hand-over, the best row as the last one of the first phase and the first one of the second, all-zero /
+    all-one descriptors (keys at both ends of the float range) at the highest rows of the first phase, and queries
+    whose two smallest both lie in one phase or one in each."""
+    rng = np.random.default_rng(9000 + nt)
+    q = rng.integers(0, 256, (320, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    last1 = min(767, nt - 1)           # last row of the insertion phase
+    t[last1] = q[0]
+    t[5] = q[1]
+    if nt > 768:
+        t[768] = q[1]                  # first row of the vote phase: the same distance as row 5, the lower row wins
+    t[last1 - 1] = q[2] ^ np.uint8(1)  # distance 8 in the first phase ...
+    if nt > 790:
+        t[790] = q[2]                  # ... beaten in the second
+        t[791] = q[2]                  # best and second best both after the hand-over, equal
+    t[last1 - 2] = 0
+    t[last1 - 3] = 0xff
+    q[3] = 0
+    q[4] = 0xff
+    q[5] = 0xff
+    q[5, 31] = 0xfe
+    q[6] = t[0]                        # row 0 and row 1 equal: second best = same distance
+    t[1] = t[0]
+    q[7] = t[nt - 1]                   # the very last row
+    m = _matcher(orb, scan)
+    idx, d1, d2 = m.knn2(q, t)
+    ridx, rd1, rd2 = orbref.knn2(q, t)
+    assert np.array_equal(idx, ridx) and np.array_equal(d1, rd1) and np.array_equal(d2, rd2)
+    assert d1[0] == 0 and d1[3] == 0 and d1[4] == 0 and d1[6] == 0 and d2[6] == 0 and idx[6] == 0
+    assert idx[1] == 5 and d1[1] == 0 and (nt <= 768 or d2[1] == 0)
+
+
+@pytest.mark.parametrize("scan", SCANS)
 def test_knn2_batched_pairs(orb, orbref, synth, scan):
     P, nq, nt = 9, 300, 400
     qs, ts = zip(*[synth.synth_descriptors(nq, nt, seed=100 + p) for p in range(P)])
