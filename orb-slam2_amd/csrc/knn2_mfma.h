@@ -16,7 +16,7 @@
 // whole scan) against one chunk of train rows, with the arguments, the keys (distance << 22 | chunk-relative
 // row) and the partial results of k_knn2, so the two kernels are interchangeable.  The waves do not cooperate:
 // lane (h, r) of a wave loads 16 bytes of row r of each 32-row tile (the wave reads the tile's 1 KB exactly once)
-// and expands them with 28 full-rate shift / mask instructions, no LDS, no barrier.  (Measured on the way here,
+// and expands them with 20 full-rate mask / shift instructions, no LDS, no barrier.  (Measured on the way here,
 // tools/mfma_valu_probe.hip and tools/knn_mm_probe.hip: an LDS stage shared by the workgroup lost more at its
 // barriers than the shared expansion saved; 8-bit integer operands need twice the instructions and twice the
 // expansion; next to a 16 x 16 instruction only two independent vector instructions issue for free, next to a
@@ -52,10 +52,21 @@
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// the four operand dwords of one instruction from the lane's word: nibble j of dword k = bit k + 4 j, as 0x2 / 0x0
+// The four operand dwords of one instruction from the lane's word of a train row: nibble j of dword k stands for
+// bit k + 4 j of the word.  The bit stays where it is inside its nibble wherever E2M1 has a value for that position
+// (0x1 = 0.5, 0x2 = 1.0, 0x4 = 2.0; 0x8 is -0, so bit 3 moves to bit 2): four masks and one shift per word.  The
+// query's nibble of the same position carries the reciprocal magnitude (kmm_query_nibbles), so every product is
+// 0 or +-1 whatever the dword.
 __device__ __forceinline__ i32x8 kmm_nibbles(uint32_t w) {
-    return i32x8{(int)((w << 1) & 0x22222222u), (int)(w & 0x22222222u), (int)((w >> 1) & 0x22222222u),
-                 (int)((w >> 2) & 0x22222222u), 0, 0, 0, 0};
+    return i32x8{(int)(w & 0x11111111u), (int)(w & 0x22222222u), (int)(w & 0x44444444u), (int)((w >> 1) & 0x44444444u),
+                 0, 0, 0, 0};
+}
+
+// The query's side: +x for a clear bit, -x for a set one (nibble bit 3 is the sign), x = 2 / 1 / 0.5 / 0.5 for dwords
+// 0 .. 3 (0x4, 0x2, 0x1, 0x1).
+__device__ __forceinline__ i32x8 kmm_query_nibbles(uint32_t w) {
+    return i32x8{(int)(((w << 3) & 0x88888888u) | 0x44444444u), (int)(((w << 2) & 0x88888888u) | 0x22222222u),
+                 (int)(((w << 1) & 0x88888888u) | 0x11111111u), (int)((w & 0x88888888u) | 0x11111111u), 0, 0, 0, 0};
 }
 
 __global__ __launch_bounds__(256) void k_knn2_mm(const uint32_t* __restrict__ q, int nq, long long q_pair_words,
@@ -70,7 +81,7 @@ __global__ __launch_bounds__(256) void k_knn2_mm(const uint32_t* __restrict__ q,
     const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
 #endif
 
-    // ---- the lane's share of the two query tiles: +1 (0x2) for a clear bit, -1 (0xA) for a set one ----
+    // ---- the lane's share of the two query tiles ----
     i32x8 bq[2][4];
 #pragma unroll
     for (int qt = 0; qt < 2; qt++) {
@@ -78,11 +89,7 @@ __global__ __launch_bounds__(256) void k_knn2_mm(const uint32_t* __restrict__ q,
         const uint4 w4 = *(const uint4*)(q + (long long)pair * q_pair_words + (long long)min(qi, nq - 1) * 8 + 4 * h);
         const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) {
-            const i32x8 b = kmm_nibbles(w[ks]);
-            bq[qt][ks] = i32x8{(int)(((uint32_t)b[0] << 2) | 0x22222222u), (int)(((uint32_t)b[1] << 2) | 0x22222222u),
-                               (int)(((uint32_t)b[2] << 2) | 0x22222222u), (int)(((uint32_t)b[3] << 2) | 0x22222222u), 0, 0, 0, 0};
-        }
+        for (int ks = 0; ks < 4; ks++) bq[qt][ks] = kmm_query_nibbles(w[ks]);
     }
 
     const int j0 = chunk * chunk_rows;
