@@ -69,6 +69,16 @@ __device__ __forceinline__ i32x8 kmm_query_nibbles(uint32_t w) {
                  (int)(((w << 1) & 0x88888888u) | 0x11111111u), (int)((w & 0x88888888u) | 0x11111111u), 0, 0, 0, 0};
 }
 
+// The second smallest of the four keys the two lanes of a query (lane and lane ^ 32) hold as (best, best2), the same
+// value in both lanes.  v_permlane32_swap exchanges the upper half of one register with the lower half of another;
+// applied to two copies of a value it leaves "the lower lane's" in one and "the upper lane's" in the other, and the
+// result is symmetric in the two, so no lane needs to know which half it is in (and nothing goes through LDS).
+__device__ __forceinline__ uint32_t kmm_query_second(uint32_t best, uint32_t best2) {
+    const auto b = __builtin_amdgcn_permlane32_swap(best, best, false, false);
+    const auto b2 = __builtin_amdgcn_permlane32_swap(best2, best2, false, false);
+    return min(max(b[0], b[1]), min(b2[0], b2[1]));
+}
+
 __global__ __launch_bounds__(256) void k_knn2_mm(const uint32_t* __restrict__ q, int nq, long long q_pair_words,
                                                   const uint32_t* __restrict__ t, int nt, long long t_pair_words,
                                                   int chunk_rows, int nchunks, int idx_base, uint2* __restrict__ part,
@@ -193,8 +203,7 @@ __global__ __launch_bounds__(256) void k_knn2_mm(const uint32_t* __restrict__ q,
                 }
                 // The threshold is the second-smallest key of the QUERY, i.e. over both lanes that share it: the
                 // other lane's keys are of rows before this tile, so a result that ties with it loses on the row.
-                const uint32_t ob = (uint32_t)__shfl_xor((int)best[qt], 32), ob2 = (uint32_t)__shfl_xor((int)best2[qt], 32);
-                const uint32_t u2 = min(max(best[qt], ob), min(best2[qt], ob2));
+                const uint32_t u2 = kmm_query_second(best[qt], best2[qt]);
                 thr[qt] = u2 == KNN_NONE ? (float)KMM_THR_NONE : (float)((int)(u2 >> KNN_IDX_BITS) - KMM_BIAS);
             }
         }
@@ -220,8 +229,7 @@ __global__ __launch_bounds__(256) void k_knn2_mm(const uint32_t* __restrict__ q,
                                                         : ((u1 >> KMM_FKEY_BITS) << KNN_IDX_BITS) + (u1 & (KMM_FKEY_SCALE - 1));
                 best2[qt] = fk2[qt] == __builtin_inff() ? KNN_NONE
                                                          : ((u2 >> KMM_FKEY_BITS) << KNN_IDX_BITS) + (u2 & (KMM_FKEY_SCALE - 1));
-                const uint32_t ob = (uint32_t)__shfl_xor((int)best[qt], 32), ob2 = (uint32_t)__shfl_xor((int)best2[qt], 32);
-                const uint32_t s2 = min(max(best[qt], ob), min(best2[qt], ob2));
+                const uint32_t s2 = kmm_query_second(best[qt], best2[qt]);
                 thr[qt] = s2 == KNN_NONE ? (float)KMM_THR_NONE : (float)((int)(s2 >> KNN_IDX_BITS) - KMM_BIAS);
             }
         }
