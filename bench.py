@@ -203,6 +203,31 @@ def extract_roofline(wl, prof_steps):
                            "frac": round(path_bytes / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if path_ms > 0 else 0.0}}, N_frame
 
 
+class StdoutGuard:
+    """The contract is ONE JSON line on stdout.  RCCL prints a version banner to the process's stdout when its first
+    communicator comes up, so while collectives may initialise, file descriptor 1 points at stderr; emit() puts the
+    real stdout back and prints the line."""
+
+    def __init__(self):
+        self.saved = None
+
+    def divert(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def emit(self, line):
+        sys.stdout.flush()
+        if self.saved is not None:
+            os.dup2(self.saved, 1)
+            os.close(self.saved)
+            self.saved = None
+        print(json.dumps(line), flush=True)
+
+
+STDOUT = StdoutGuard()
+
+
 class Watchdog:
     """The legs that run after the headline measurement must not be able to lose it: if they have not
     finished after `seconds` (a collective that never completes, a stuck host thread), rank 0 prints the
@@ -222,7 +247,7 @@ class Watchdog:
     def fire(self):
         if self.rank == 0 and self.line is not None:
             self.line["extra"] = {"error": "the legs after the headline measurement did not finish within %d s" % self.seconds}
-            print(json.dumps(self.line), flush=True)
+            STDOUT.emit(self.line)
         os._exit(0)
 
     def cancel(self):
@@ -267,6 +292,7 @@ def main():
     torch.cuda.set_device(dev)
     use_dist = world > 1 or args.dist_legs
     if use_dist:
+        STDOUT.divert()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
@@ -338,7 +364,7 @@ def main():
             dog.cancel()
             if rank == 0:
                 out["extra"] = {"error": "a leg after the headline measurement raised %s: %s" % (type(ex).__name__, ex)}
-                print(json.dumps(out), flush=True)
+                STDOUT.emit(out)
             sys.stderr.write("rank %d: %r\n" % (rank, ex))
             sys.stderr.flush()
             os._exit(0)  # no collective teardown: the other ranks may be anywhere
@@ -347,7 +373,7 @@ def main():
     barrier()
     dog.cancel()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        STDOUT.emit(out)
     if use_dist:
         dist.destroy_process_group()
 
