@@ -694,6 +694,17 @@ int orbhip_extractor_stage_times(orbhip_extractor* e, float* ms_out, int* launch
 void* orbhip_extractor_stream(orbhip_extractor* e) { return e ? (void*)e->stream : nullptr; }
 float orbhip_last_elapsed_ms(orbhip_extractor* e) { return e ? e->last_ms : 0.f; }
 
+// true if the byte at p lies in page-locked host memory the device can copy from directly (hipHostMalloc,
+// hipHostRegister, a pinned tensor); pageable memory reports "unregistered" or an error, depending on the runtime
+static bool host_page_locked(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
 int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int batch, int rows, int cols, ptrdiff_t row_stride,
                          ptrdiff_t frame_stride, OrbKeypoint* kp_out, uint8_t* desc_out, int cap, int* n_out) {
     int rc = check_call(e, batch, rows, cols, cap);
@@ -714,16 +725,22 @@ int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int batch, in
     if ((rc = e->h_outblk.ensure(blk_bytes))) return rc;
     uint8_t* const dblk = e->d_outblk.as<uint8_t>();
     const uint8_t* const hblk = e->h_outblk.as<uint8_t>();
+    // Packed frames in page-locked memory of the caller's are copied from where they lie; anything else goes through
+    // the handle's page-locked staging first.  (One frame per call always stages: its queue is a captured graph
+    // with the staging address in it.)
+    const bool direct = batch > 1 && row_stride == cols && frame_stride == (ptrdiff_t)img_bytes && host_page_locked(imgs) &&
+                        host_page_locked(imgs + img_bytes * (size_t)batch - 1);
     for (int f0 = 0; f0 < batch; f0 += chunk) {
         const int b = std::min(chunk, batch - f0);
         // frames -> page-locked staging (packed rows), one host-to-device copy
-        uint8_t* hin = e->h_img.as<uint8_t>();
-        for (int f = 0; f < b; f++) {
+        const uint8_t* hin = direct ? imgs + (size_t)f0 * img_bytes : e->h_img.as<uint8_t>();
+        uint8_t* const stage = e->h_img.as<uint8_t>();
+        for (int f = 0; f < b && !direct; f++) {
             const uint8_t* src = imgs + (ptrdiff_t)(f0 + f) * frame_stride;
             if (row_stride == cols) {
-                memcpy(hin + (size_t)f * img_bytes, src, img_bytes);
+                memcpy(stage + (size_t)f * img_bytes, src, img_bytes);
             } else {
-                for (int r = 0; r < rows; r++) memcpy(hin + (size_t)f * img_bytes + (size_t)r * cols, src + (ptrdiff_t)r * row_stride, cols);
+                for (int r = 0; r < rows; r++) memcpy(stage + (size_t)f * img_bytes + (size_t)r * cols, src + (ptrdiff_t)r * row_stride, cols);
             }
         }
         const size_t used = desc_off + (size_t)32 * cap * b;

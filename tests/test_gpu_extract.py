@@ -367,3 +367,22 @@ def test_sse2_gaussian_profile(orb, orbref, synth):
     assert np.array_equal(d2, d0)
     with pytest.raises(orb.OrbhipError):
         ext.set_gaussian_profile(7)
+
+
+def test_batch_from_page_locked_host_memory(orb, synth):
+    """orbhip_extract_batch copies packed frames that lie in page-locked host memory straight to the device and
+    stages pageable ones: both must give the same keypoints and descriptors, with a batch that the handle cuts
+    into chunks (the last one partial)."""
+    import ctypes as C
+    import torch
+    w, h, nf, b = 320, 240, 500, 5
+    imgs = np.stack([synth.synth_image(w, h, 700 + i) for i in range(b)])
+    ext = orb.ORBextractor(nf, 1.2, 8, 1, 20, max_width=w, max_height=h, max_batch=2)
+    pageable = ext.extract_batch(imgs)
+    pinned = torch.from_numpy(imgs).pin_memory()
+    view = np.ctypeslib.as_array((C.c_uint8 * imgs.size).from_address(pinned.data_ptr())).reshape(imgs.shape)
+    assert view.ctypes.data == pinned.data_ptr()
+    locked = ext.extract_batch(view)
+    assert len(pageable) == len(locked) == b
+    for (kp0, d0), (kp1, d1) in zip(pageable, locked):
+        assert len(kp0) > 0 and kp0.tobytes() == kp1.tobytes() and np.array_equal(d0, d1)
