@@ -735,19 +735,32 @@ int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int batch, in
         // frames -> page-locked staging (packed rows), one host-to-device copy
         const uint8_t* hin = direct ? imgs + (size_t)f0 * img_bytes : e->h_img.as<uint8_t>();
         uint8_t* const stage = e->h_img.as<uint8_t>();
-        for (int f = 0; f < b && !direct; f++) {
-            const uint8_t* src = imgs + (ptrdiff_t)(f0 + f) * frame_stride;
-            if (row_stride == cols) {
-                memcpy(stage + (size_t)f * img_bytes, src, img_bytes);
-            } else {
-                for (int r = 0; r < rows; r++) memcpy(stage + (size_t)f * img_bytes + (size_t)r * cols, src + (ptrdiff_t)r * row_stride, cols);
+        // Staged frames go to the device in blocks of about 8 MB as soon as a block is packed, so that the copy
+        // engine works while the host packs the next block (one frame per call keeps its single copy: it is part
+        // of the captured graph).
+        const int blk = batch > 1 ? std::max(1, (int)(((size_t)8 << 20) / img_bytes)) : b;
+        bool h2d_queued = false;
+        for (int fb = 0; fb < b && !direct; fb += blk) {
+            const int nb = std::min(blk, b - fb);
+            for (int f = fb; f < fb + nb; f++) {
+                const uint8_t* src = imgs + (ptrdiff_t)(f0 + f) * frame_stride;
+                if (row_stride == cols) {
+                    memcpy(stage + (size_t)f * img_bytes, src, img_bytes);
+                } else {
+                    for (int r = 0; r < rows; r++) memcpy(stage + (size_t)f * img_bytes + (size_t)r * cols, src + (ptrdiff_t)r * row_stride, cols);
+                }
+            }
+            if (batch > 1) {
+                HIPCHK(hipMemcpyAsync(e->d_img.as<uint8_t>() + (size_t)fb * img_bytes, stage + (size_t)fb * img_bytes,
+                                      img_bytes * nb, hipMemcpyHostToDevice, e->stream));
+                h2d_queued = true;
             }
         }
         const size_t used = desc_off + (size_t)32 * cap * b;
         // the queue of one chunk: image in, kernel sequence, error flags and the whole output block back (ONE
         // synchronisation; the counts say how much of the block is valid)
         auto enqueue = [&]() -> int {
-            HIPCHK(hipMemcpyAsync(e->d_img.p, hin, img_bytes * b, hipMemcpyHostToDevice, e->stream));
+            if (!h2d_queued) HIPCHK(hipMemcpyAsync(e->d_img.p, hin, img_bytes * b, hipMemcpyHostToDevice, e->stream));
             const int r2 = orbhip_extract_batch_device(e, e->d_img.as<uint8_t>(), b, rows, cols, cols, (ptrdiff_t)img_bytes,
                                                        (OrbKeypoint*)(dblk + kp_off), dblk + desc_off, cap, (int*)(dblk + n_off));
             if (r2) return r2;
