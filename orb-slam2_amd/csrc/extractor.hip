@@ -98,6 +98,9 @@ struct orbhip_extractor {
     std::vector<hipStream_t> workers;
     std::vector<hipEvent_t> worker_done;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // host-buffer batches of 512 frames and more go to the device in pieces on a copy stream of their own
+    hipStream_t copy_stream = nullptr;
+    std::vector<hipEvent_t> copy_done;
     float last_ms = 0.f;
     int max_batch;
     // per-stage timing (bench instrumentation): events bracket each kernel group of a chunk
@@ -574,6 +577,8 @@ void orbhip_extractor_destroy(orbhip_extractor* e) {
     for (hipEvent_t ev : e->prof_ev) hipEventDestroy(ev);
     for (hipEvent_t ev : e->worker_done) hipEventDestroy(ev);
     for (hipStream_t st : e->workers) hipStreamDestroy(st);
+    for (hipEvent_t ev : e->copy_done) hipEventDestroy(ev);
+    if (e->copy_stream) hipStreamDestroy(e->copy_stream);
     if (e->ev0) hipEventDestroy(e->ev0);
     if (e->ev1) hipEventDestroy(e->ev1);
     if (e->stream) hipStreamDestroy(e->stream);
@@ -740,7 +745,47 @@ int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int batch, in
         // of the captured graph).
         const int blk = batch > 1 ? std::max(1, (int)(((size_t)8 << 20) / img_bytes)) : b;
         bool h2d_queued = false;
-        for (int fb = 0; fb < b && !direct; fb += blk) {
+        const size_t used = desc_off + (size_t)32 * cap * b;
+        // Large chunks run as pieces of at least 256 frames: a piece's frames travel on the copy stream, its kernels wait
+        // for them alone, so the kernels of one piece run under the copy (and, for staged input, the packing) of the
+        // next.  (The stage taps of the debug interface see the last piece only; chunks below 512 frames run whole.)
+        const int pieces = e->profiling ? 1 : std::min(8, b / 256);
+        bool pipelined = false;
+        if (pieces >= 2) {
+            if (!e->copy_stream) HIPCHK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+            while ((int)e->copy_done.size() < 8) {
+                hipEvent_t ev;
+                HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                e->copy_done.push_back(ev);
+            }
+            for (int k = 0; k < pieces; k++) {
+                const int s0 = (int)((long long)b * k / pieces) & ~7, s1 = k + 1 == pieces ? b : (int)((long long)b * (k + 1) / pieces) & ~7;
+                const uint8_t* src = imgs + (size_t)(f0 + s0) * img_bytes;
+                if (!direct) {
+                    for (int f = s0; f < s1; f++) {
+                        const uint8_t* fr = imgs + (ptrdiff_t)(f0 + f) * frame_stride;
+                        if (row_stride == cols) {
+                            memcpy(stage + (size_t)f * img_bytes, fr, img_bytes);
+                        } else {
+                            for (int r = 0; r < rows; r++) memcpy(stage + (size_t)f * img_bytes + (size_t)r * cols, fr + (ptrdiff_t)r * row_stride, cols);
+                        }
+                    }
+                    src = stage + (size_t)s0 * img_bytes;
+                }
+                HIPCHK(hipMemcpyAsync(e->d_img.as<uint8_t>() + (size_t)s0 * img_bytes, src, img_bytes * (size_t)(s1 - s0),
+                                      hipMemcpyHostToDevice, e->copy_stream));
+                HIPCHK(hipEventRecord(e->copy_done[k], e->copy_stream));
+                HIPCHK(hipStreamWaitEvent(e->stream, e->copy_done[k], 0));
+                if ((rc = orbhip_extract_batch_device(e, e->d_img.as<uint8_t>() + (size_t)s0 * img_bytes, s1 - s0, rows, cols, cols,
+                                                      (ptrdiff_t)img_bytes, (OrbKeypoint*)(dblk + kp_off) + (size_t)s0 * cap,
+                                                      dblk + desc_off + (size_t)32 * cap * s0, cap, (int*)(dblk + n_off) + s0)))
+                    return rc;
+            }
+            HIPCHK(hipMemcpyAsync(dblk, e->d_err.p, sizeof(int), hipMemcpyDeviceToDevice, e->stream));
+            HIPCHK(hipMemcpyAsync((void*)hblk, dblk, used, hipMemcpyDeviceToHost, e->stream));
+            pipelined = true;
+        }
+        for (int fb = 0; fb < b && !direct && !pipelined; fb += blk) {
             const int nb = std::min(blk, b - fb);
             for (int f = fb; f < fb + nb; f++) {
                 const uint8_t* src = imgs + (ptrdiff_t)(f0 + f) * frame_stride;
@@ -756,7 +801,6 @@ int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int batch, in
                 h2d_queued = true;
             }
         }
-        const size_t used = desc_off + (size_t)32 * cap * b;
         // the queue of one chunk: image in, kernel sequence, error flags and the whole output block back (ONE
         // synchronisation; the counts say how much of the block is valid)
         auto enqueue = [&]() -> int {
@@ -801,7 +845,7 @@ int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int batch, in
                 replayed = true;
             }
         }
-        if (!replayed && (rc = enqueue())) return rc;
+        if (!replayed && !pipelined && (rc = enqueue())) return rc;
         if ((rc = wait_and_collect_times(e))) return rc;
         const int herr = *(const int*)hblk;
         if (herr) {

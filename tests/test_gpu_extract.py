@@ -386,3 +386,26 @@ def test_batch_from_page_locked_host_memory(orb, synth):
     assert len(pageable) == len(locked) == b
     for (kp0, d0), (kp1, d1) in zip(pageable, locked):
         assert len(kp0) > 0 and kp0.tobytes() == kp1.tobytes() and np.array_equal(d0, d1)
+
+
+def test_large_host_batch_runs_in_pieces(orb, synth):
+    """A host-buffer batch of 512 frames and more is cut into pieces whose copies run on a stream of their own under
+    the kernels of the piece before: same keypoints and descriptors as the same frames through a handle that takes
+    them in chunks of 100 (never in pieces), from pageable and from page-locked memory, with a frame count that is not
+    a multiple of anything."""
+    import ctypes as C
+    import torch
+    w, h, nf, b = 160, 120, 200, 603
+    base = [synth.synth_image(w, h, 900 + i) for i in range(24)]
+    imgs = np.stack([np.roll(base[i % 24], i // 24, axis=1) for i in range(b)])
+    whole = orb.ORBextractor(nf, 1.2, 4, 1, 20, max_width=w, max_height=h, max_batch=b)
+    chunked = orb.ORBextractor(nf, 1.2, 4, 1, 20, max_width=w, max_height=h, max_batch=100)
+    ref = chunked.extract_batch(imgs)
+    got = whole.extract_batch(imgs)
+    pinned = torch.from_numpy(imgs).pin_memory()
+    view = np.ctypeslib.as_array((C.c_uint8 * imgs.size).from_address(pinned.data_ptr())).reshape(imgs.shape)
+    got_locked = whole.extract_batch(view)
+    assert len(ref) == len(got) == len(got_locked) == b
+    for (kp0, d0), (kp1, d1), (kp2, d2) in zip(ref, got, got_locked):
+        assert len(kp0) > 0 and kp0.tobytes() == kp1.tobytes() == kp2.tobytes()
+        assert np.array_equal(d0, d1) and np.array_equal(d0, d2)
