@@ -75,7 +75,8 @@ int orbhip_extract(orbhip_extractor* e, const uint8_t* img, int rows, int cols, 
  * imgs + f * frame_stride).  Outputs are per frame at stride cap: kp_out[batch*cap],
  * desc_out[batch*cap*32], n_out[batch].  Blocking.  Packed frames (row_stride == cols, frame_stride ==
  * rows * cols) that lie in page-locked host memory are copied to the device from where they lie; any other
- * input is first packed into the handle's own page-locked staging (about 1.5 times the time per call). */
+ * input is first packed into the handle's own page-locked staging (about twice the time per call).  Chunks of
+ * 512 frames and more run in pieces whose copies overlap the kernels of the piece before. */
 int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int batch, int rows, int cols,
                          ptrdiff_t row_stride, ptrdiff_t frame_stride, OrbKeypoint* kp_out,
                          uint8_t* desc_out, int cap, int* n_out);
