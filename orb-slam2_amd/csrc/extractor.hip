@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/orbhip.h"
@@ -762,14 +763,34 @@ int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int batch, in
                 const int s0 = (int)((long long)b * k / pieces) & ~7, s1 = k + 1 == pieces ? b : (int)((long long)b * (k + 1) / pieces) & ~7;
                 const uint8_t* src = imgs + (size_t)(f0 + s0) * img_bytes;
                 if (!direct) {
-                    for (int f = s0; f < s1; f++) {
-                        const uint8_t* fr = imgs + (ptrdiff_t)(f0 + f) * frame_stride;
-                        if (row_stride == cols) {
-                            memcpy(stage + (size_t)f * img_bytes, fr, img_bytes);
-                        } else {
-                            for (int r = 0; r < rows; r++) memcpy(stage + (size_t)f * img_bytes + (size_t)r * cols, fr + (ptrdiff_t)r * row_stride, cols);
+                    // one thread packs about 10 GB/s, a fifth of what the link moves: a piece is packed by a few
+                    // threads (ORBHIP_HOST_THREADS, default 4; 1 = the calling thread alone)
+                    auto pack = [&](int fa, int fz) {
+                        for (int f = fa; f < fz; f++) {
+                            const uint8_t* fr = imgs + (ptrdiff_t)(f0 + f) * frame_stride;
+                            if (row_stride == cols) {
+                                memcpy(stage + (size_t)f * img_bytes, fr, img_bytes);
+                            } else {
+                                for (int r = 0; r < rows; r++) memcpy(stage + (size_t)f * img_bytes + (size_t)r * cols, fr + (ptrdiff_t)r * row_stride, cols);
+                            }
+                        }
+                    };
+                    static const int host_threads = [] {
+                        const char* env = getenv("ORBHIP_HOST_THREADS");
+                        return std::max(1, std::min(env ? atoi(env) : 4, 16));
+                    }();
+                    const int nt = std::min(host_threads, s1 - s0);
+                    std::vector<std::thread> helpers;
+                    for (int t = 1; t < nt; t++) {
+                        const int fa = s0 + (int)((long long)(s1 - s0) * t / nt), fz = s0 + (int)((long long)(s1 - s0) * (t + 1) / nt);
+                        try {
+                            helpers.emplace_back(pack, fa, fz);
+                        } catch (...) {
+                            pack(fa, fz);  // no thread to be had: the caller's thread does the share itself
                         }
                     }
+                    pack(s0, s0 + (int)((long long)(s1 - s0) / nt));
+                    for (std::thread& th : helpers) th.join();
                     src = stage + (size_t)s0 * img_bytes;
                 }
                 HIPCHK(hipMemcpyAsync(e->d_img.as<uint8_t>() + (size_t)s0 * img_bytes, src, img_bytes * (size_t)(s1 - s0),
