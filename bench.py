@@ -152,6 +152,43 @@ def _pmc_traffic(kernel, wl):
     return None
 
 
+FULL_RATE_CYCLES = 2.3  # SIMD cycles per wave64 instruction of the full-rate VALU class on this part (tools/valu_probe.hip)
+SHADER_CLOCK_HZ = 2.4e9
+SIMDS = 256 * 4
+
+
+def _valu_roofline(kernel, wl, avg_launch_ms, pixels_per_launch):
+    """Instruction-issue roofline of `kernel` beside the HBM one.  The wave-instruction count per launch comes from
+    the latest committed SQ counter summary of this same workload (profiles/*_pmc_sq.json; counters cannot be read
+    inside the timed run), the launch duration is the one measured live.  cycles_per_instr = SIMD cycles the launch
+    had (1024 SIMDs x duration x 2.4 GHz) per VALU wave instruction it issued; a kernel made only of full-rate
+    instructions that never waits would sit at 2.3."""
+    import glob
+    want = "%d x %dx%d frames, %d features" % (wl.batch, wl.w, wl.h, wl.nf)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_sq.json")), reverse=True):
+        if "matcher" in os.path.basename(f):
+            continue
+        try:
+            j = json.load(open(f))
+            if want not in j.get("source", ""):
+                continue
+            k = next((v for n, v in j["kernels"].items() if n.split("<")[0] == kernel), None)
+            if not k or avg_launch_ms <= 0:
+                continue
+            insts = float(k["SQ_INSTS_VALU"])
+            avail = SIMDS * avg_launch_ms * 1e-3 * SHADER_CLOCK_HZ
+            cpi = avail / insts
+            lds_act, lds_conf = float(k.get("SQ_LDS_IDX_ACTIVE", 0)), float(k.get("SQ_LDS_BANK_CONFLICT", 0))
+            return {"wave_instr_per_launch": insts, "lane_instr_per_pixel": round(insts * 64 / pixels_per_launch, 2),
+                    "simd_cycles_available": float("%.4g" % avail), "cycles_per_instr": round(cpi, 3),
+                    "full_rate_cycles_per_instr": FULL_RATE_CYCLES, "frac_of_full_rate": round(FULL_RATE_CYCLES / cpi, 4),
+                    "lds_bank_conflict_share": round(lds_conf / lds_act, 4) if lds_act else None,
+                    "counters_from": os.path.basename(f)}
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
+
+
 def extract_roofline(wl, prof_steps):
     """Stage durations from HIP events on the library's stream (single-stream profiling pass of the
     library) against the algorithmic bytes of each kernel group: the 5 B/pixel + 60 B/keypoint of the
@@ -195,6 +232,7 @@ def extract_roofline(wl, prof_steps):
     return {"bound": "hbm", "kernel": names[dominant], "stage": dominant, "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": _pmc_traffic(names[dominant], wl),
+            "valu": _valu_roofline(names[dominant], wl, avg_launch_ms, P * wl.batch / max(launches, 1)),
             "launches_per_step": launches, "avg_launch_ms": round(avg_launch_ms, 5),
             "algorithmic_bytes_per_launch": int(bytes_per_launch),
             "stages": stages,
@@ -254,6 +292,65 @@ class Watchdog:
         self.timer.cancel()
 
 
+def rank_environment(base_env, rank, world, port):
+    """Environment of rank `rank` of `world` on this node: what torch.distributed.run would set."""
+    env = dict(base_env)
+    env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs between processes on this driver
+    return env
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(world, argv, grace=30.0):
+    """Starts one child process per rank (this file, same arguments), forwards rank 0's stdout (the ONE JSON line)
+    to this process's stdout and everything else to stderr, and returns the worst exit code.  The parent never
+    touches the GPU; no process that has touched it is ever replaced.  If a rank dies, the others get `grace`
+    seconds to finish (their collectives cannot complete any more) and are then terminated by PID."""
+    port = free_port()
+    me = os.path.abspath(__file__)
+    procs = []
+    for r in range(world):
+        procs.append(subprocess.Popen([sys.executable, "-u", me] + list(argv), env=rank_environment(os.environ, r, world, port),
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+
+    def forward():
+        for line in procs[0].stdout:
+            sys.stdout.write(line.decode(errors="replace"))
+            sys.stdout.flush()
+
+    fw = threading.Thread(target=forward, daemon=True)
+    fw.start()
+    first_failure = None
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        failed = [p for p in procs if p.poll() not in (None, 0)]
+        if failed and first_failure is None:
+            first_failure = time.monotonic()
+        if first_failure is not None and time.monotonic() - first_failure > grace:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            time.sleep(5.0)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+    fw.join(10.0)
+    codes = [p.wait() for p in procs]
+    worst = max((c for c in codes), key=lambda c: (c != 0, abs(c)))
+    if worst != 0:
+        sys.stderr.write("bench.py: exit codes of the %d ranks: %s\n" % (world, codes))
+    return worst if 0 <= worst < 256 else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -270,16 +367,26 @@ def main():
     ap.add_argument("--dist-legs", action="store_true",
                     help="run the multi-rank legs even with one rank (rehearsal of the N > 1 code on one GPU)")
     ap.add_argument("--legs-timeout", type=int, default=900, help="seconds the legs after the headline may take")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default=os.environ.get("ORBHIP_BENCH_BACKEND", "nccl"),
+                    help="torch.distributed backend of the N > 1 run.  nccl (RCCL) is the measured configuration; gloo is a "
+                         "rehearsal of the multi-rank code on fewer GPUs than ranks (ranks share devices, records travel "
+                         "through host memory, the library's own RCCL communicator is left out)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process starts the N ranks itself.  It has not
+        # touched the GPU (no HIP call, no torch.cuda, liborbhip.so not loaded) and never does.
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if args.gpus != 1 and world == 1:
-            raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
-                             "--nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
+    if os.environ.get("ORBHIP_BENCH_LAUNCH_SELFTEST"):
+        # tests/test_bench_launcher.py: what a rank was started with, before anything heavy is imported
+        print(json.dumps({"rank": rank, "local_rank": local_rank, "world": world, "master": os.environ.get("MASTER_ADDR"),
+                          "port": os.environ.get("MASTER_PORT"), "steps": args.steps}), flush=True)
+        sys.exit(int(os.environ.get("ORBHIP_BENCH_LAUNCH_SELFTEST_RC_RANK%d" % rank, "0")))
 
     orb = importlib.import_module("orb-slam2_amd")
     orb._lib.lib()  # fails loudly if liborbhip.so is missing
@@ -291,11 +398,18 @@ def main():
     dev = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev)
     use_dist = world > 1 or args.dist_legs
+    gloo = args.backend == "gloo"
+    if world > torch.cuda.device_count() and not gloo:
+        raise SystemExit("%d ranks on %d GPUs: RCCL needs one GPU per rank (--backend gloo rehearses the multi-rank code "
+                         "with ranks sharing devices)" % (world, torch.cuda.device_count()))
     if use_dist:
         STDOUT.divert()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+        if gloo:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
 
     def barrier():
         if use_dist:
@@ -304,7 +418,7 @@ def main():
     def max_over_ranks(x):
         if not use_dist:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device="cuda:%d" % dev)
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if gloo else "cuda:%d" % dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -336,7 +450,9 @@ def main():
                "config": {"workload": "batch of %d synthetic %dx%d frames per GPU, %d features/frame, 8 levels, scale 1.2, "
                                       "full extract+describe" % (args.batch, args.width, args.height, args.features),
                           "frames_per_gpu_per_step": args.batch, "keypoints_per_frame": round(N_frame, 1),
-                          "parallelism": "frame-batch sharding x%d, no data-path collective" % world},
+                          "parallelism": "frame-batch sharding x%d, no data-path collective" % world,
+                          "ranks": world, "backend": ("gloo (rehearsal: %d ranks on %d GPU(s))" % (world, torch.cuda.device_count()))
+                          if gloo and use_dist else ("nccl (RCCL)" if use_dist else None)},
                "roofline": roofline, "cpu_baseline": None, "extra": {}}
     dog.arm(out)
 
@@ -357,7 +473,7 @@ def main():
     if not args.no_extra:
         try:
             if use_dist:
-                legs = dist_legs(orb, torch, dist, dev, rank, world, barrier, max_over_ranks)
+                legs = dist_legs(orb, torch, dist, dev, rank, world, barrier, max_over_ranks, gloo)
             else:
                 legs = single_gpu_legs(orb, torch, dev, wl)
         except Exception as ex:  # a leg that raises must not lose the headline measurement either
@@ -569,7 +685,13 @@ def single_gpu_legs(orb, torch, dev, wl0):
     m.set_scan_kernel("popcount")
     best_pc = knn_pairs_leg(orb, torch, dev, m, pairs, nq, nt, reps=3)[0]
     m.set_scan_kernel("matrix")
-    res["hamming_knn2"]["popcount_kernel_comparisons_per_sec"] = float("%.4g" % (pairs * nq * nt / (best_pc * 1e-3)))
+    rate_pc = pairs * nq * nt / (best_pc * 1e-3)
+    res["hamming_knn2"]["popcount_kernel_comparisons_per_sec"] = float("%.4g" % rate_pc)
+    # the xor + popcount kernel against the popcount rate the device sustains (8 v_bcnt lane-ops per comparison); an
+    # xor + popcount stream cannot exceed 0.64 of it (8 x 4.05 of every 8 x 4.05 + 8 x 2.3 issue cycles)
+    res["hamming_knn2"]["popcount_kernel_roofline"] = {
+        "bound": "valu", "kernel": "k_knn2", "achieved": float("%.4g" % (rate_pc * 8)), "peak": float("%.4g" % r_bcnt),
+        "unit": "v_bcnt lane-ops/s", "frac": round(rate_pc * 8 / r_bcnt, 4) if r_bcnt else None, "ceiling_of_the_formulation": 0.64}
     del q, t, o
     # ---- frame-vs-map shard: 4000 queries against the 1.25 M map rows one GPU of eight owns ---------
     nq2, nt2 = 4000, 1250000
@@ -608,9 +730,11 @@ def single_gpu_legs(orb, torch, dev, wl0):
 # N > 1: the rank-local legs of the multi-GPU configurations
 # ------------------------------------------------------------------------------------------------
 
-def dist_legs(orb, torch, dist, dev, rank, world, barrier, max_over_ranks):
+def dist_legs(orb, torch, dist, dev, rank, world, barrier, max_over_ranks, gloo=False):
     """Every rank runs these; rank 0 returns the record.  Timing as for the headline: barrier and device
-    synchronisation on both sides, MAX over ranks."""
+    synchronisation on both sides, MAX over ranks.  gloo: rehearsal on fewer GPUs than ranks — the per-shard records
+    travel through host memory (gloo all-gather) into the device merge, and the library's own RCCL communicator,
+    which needs one GPU per rank, is left out."""
     cuda = "cuda:%d" % dev
     shard_range = orb.sharded.shard_range
     res = {"ranks": world}
@@ -698,13 +822,16 @@ def dist_legs(orb, torch, dist, dev, rank, world, barrier, max_over_ranks):
     parts_local = torch.zeros((3, nq), dtype=torch.int32, device=cuda)
     parts_all = torch.zeros((world, 3, nq), dtype=torch.int32, device=cuda)
     torch.cuda.synchronize()
-    comm = orb.sharded.Communicator.from_torch_distributed(dist, dev)
     steps = 5
-    dt_c = timed(lambda: orb.sharded.knn2_sharded_rccl(m, comm, dq, nq, shard, e - a, a, out_c), m.synchronize, steps, warmup=6)
     dt_t = timed(lambda: orb.sharded.knn2_sharded(m, dq, nq, shard, e - a, a, parts_local, parts_all, out_t, dist=dist),
                  m.synchronize, steps, warmup=3)
-    comm.close()
-    same = torch.tensor([int(torch.equal(out_c, out_t))], dtype=torch.int32, device=cuda)
+    if gloo:
+        out_c, dt_c = out_t, dt_t
+    else:
+        comm = orb.sharded.Communicator.from_torch_distributed(dist, dev)
+        dt_c = timed(lambda: orb.sharded.knn2_sharded_rccl(m, comm, dq, nq, shard, e - a, a, out_c), m.synchronize, steps, warmup=6)
+        comm.close()
+    same = torch.tensor([int(torch.equal(out_c, out_t))], dtype=torch.int32, device="cpu" if gloo else cuda)
     dist.all_reduce(same, op=dist.ReduceOp.MIN)
     if rank == 0:
         orbref = oracle()
@@ -725,8 +852,10 @@ def dist_legs(orb, torch, dist, dev, rank, world, barrier, max_over_ranks):
             "scaling": "strong", "nq": nq, "map_rows": NT, "rows_this_rank": e - a, "steps": steps,
             "comparisons_per_sec": float("%.4g" % rate), "ms_per_step": round(dt_c / steps * 1e3, 3),
             "roofline": knn_roofline(rate / world, r_bcnt),
-            "collective": "one ncclAllGather of 12 B x %d queries per rank over %d ranks (orbhip_knn2_sharded, the "
-                          "library's own RCCL communicator, queued on the matcher's stream)" % (nq, world),
+            "collective": ("REHEARSAL: one gloo all-gather of 12 B x %d queries per rank over %d ranks through host memory, "
+                           "device merge (orbhip_knn2_merge_device)" % (nq, world)) if gloo else
+                          ("one ncclAllGather of 12 B x %d queries per rank over %d ranks (orbhip_knn2_sharded, the "
+                           "library's own RCCL communicator, queued on the matcher's stream)" % (nq, world)),
             "torch_distributed_form": {"ms_per_step": round(dt_t / steps * 1e3, 3),
                                        "comparisons_per_sec": float("%.4g" % (nq * NT * steps / dt_t)),
                                        "collective": "one all_gather_into_tensor on the nccl backend + device merge",

@@ -170,6 +170,13 @@ int orbhip_knn2(orbhip_matcher* m, const uint8_t* q, int nq, const uint8_t* t, i
  * Reproduces the serial ascending scan exactly.  Device pointers; asynchronous. */
 int orbhip_knn2_merge_device(orbhip_matcher* m, const int32_t* d_parts, int nshards, int nq,
                              int32_t* d_idx, int32_t* d_d1, int32_t* d_d2);
+/* Host twin of orbhip_knn2_merge_device, same function on records in host memory (no GPU involved): for a host that
+ * moves the per-shard records through a transport of its own (MPI, gloo, a socket) instead of RCCL. */
+int orbhip_knn2_merge_host(const int32_t* parts, int nshards, int nq, int32_t* idx, int32_t* d1, int32_t* d2);
+/* Layout of the all-gather of orbhip_knn2_sharded: every rank contributes one record of *record_ints int32 (idx[nq],
+ * d1[nq], d2[nq]); rank r's record lies at int32 offset *slot_offset_ints of the receive buffer of *total_bytes
+ * bytes — the layout orbhip_knn2_merge_device / _host take as `parts`.  Pure host arithmetic. */
+int orbhip_knn2_gather_layout(int nq, int world, int rank, size_t* record_ints, size_t* slot_offset_ints, size_t* total_bytes);
 /* ---- Frame-versus-map matching over a map sharded across GPUs --------------------------------------
  * One process per GPU.  The map descriptors are split into index-contiguous shards (rank g owns the
  * global rows [idx_base_g, idx_base_g + nt_shard_g), rank order = index order); the queries are
@@ -259,7 +266,7 @@ int orbhip_features_in_area_device(orbhip_matcher* m, const OrbKeypoint* d_kp, c
  * other one the default of new handles): descriptor bits as 4-bit matrix operands, the distances of 32 rows x 32
  * queries from four v_mfma_f32_32x32x64_f8f6f4.  ORBHIP_SCAN_POPCOUNT: xor + popcount per lane, rows through scalar
  * loads.  Both return the same integers (ties to the lower index); no counterpart in the reference, whose
- * DescriptorDistance (src/ORBmatcher.cc:1636-1652) is a scalar bit trick. */
+ * DescriptorDistance (src/ORBmatcher.cc:1805-1821) is a scalar bit trick. */
 #define ORBHIP_SCAN_MATRIX 0
 #define ORBHIP_SCAN_POPCOUNT 1
 int orbhip_matcher_set_scan_kernel(orbhip_matcher* m, int kind);

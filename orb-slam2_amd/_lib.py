@@ -102,6 +102,8 @@ def lib():
     L.orbhip_knn2_scratch_bytes.argtypes = []
     L.orbhip_knn2.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp, vp]
     L.orbhip_knn2_merge_device.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+    L.orbhip_knn2_merge_host.argtypes = [vp, i32, i32, vp, vp, vp]
+    L.orbhip_knn2_gather_layout.argtypes = [i32, i32, i32, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
     L.orbhip_comm_unique_id.argtypes = [vp, sz]
     L.orbhip_comm_create.argtypes = [C.POINTER(vp), vp, sz, i32, i32, i32]
     L.orbhip_comm_adopt.argtypes = [C.POINTER(vp), vp, i32, i32, i32]

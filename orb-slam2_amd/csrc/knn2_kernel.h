@@ -138,6 +138,8 @@ __device__ __forceinline__ void quad_arrived(const RowQuad& g) { asm volatile(""
 // min(nt, (chunk+1)*chunk_rows)) and emits its two smallest keys per query.  With one chunk the
 // final (idx, d1, d2) are written directly.  The row quads are double-buffered in scalar registers:
 // the loads of the next group are in flight while the current one is compared.
+// (KNN_HELPERS_ONLY: a translation unit that wants the keys and folds above but not this kernel)
+#ifndef KNN_HELPERS_ONLY
 #ifndef KNN_KERNEL_NAME
 #define KNN_KERNEL_NAME k_knn2
 #endif
@@ -191,4 +193,4 @@ __global__ __launch_bounds__(256) void KNN_KERNEL_NAME(const uint32_t* __restric
         part[((long long)pair * nchunks + chunk) * nq + qi] = make_uint2(best, best2);
     }
 }
-
+#endif  // KNN_HELPERS_ONLY

@@ -26,7 +26,9 @@
 namespace {
 
 #include "knn2_kernel.h"
-#include "knn2_mfma.h"
+}  // namespace
+#include "knn2_merge.h"
+namespace {
 
 // Chunks are index-contiguous and visited in ascending order, so folding each chunk's two
 // smallest distances with the reference's update rule reproduces the serial scan.
@@ -71,23 +73,7 @@ __global__ __launch_bounds__(256) void k_knn2_merge(const int32_t* __restrict__ 
                                                     int32_t* __restrict__ o_d2) {
     const int qi = blockIdx.x * 256 + threadIdx.x;
     if (qi >= nq) return;
-    int best = INT_MAX, best2 = INT_MAX, idx = -1;
-    for (int s = 0; s < nshards; s++) {
-        const int32_t* p = parts + (long long)s * 3 * nq;
-        const int i = p[qi], d1 = p[nq + qi], d2 = p[2 * nq + qi];
-        if (i < 0) continue;
-        if (d1 < best) {
-            best2 = best;
-            best = d1;
-            idx = i;
-        } else if (d1 < best2) {
-            best2 = d1;
-        }
-        if (d2 < best2) best2 = d2;
-    }
-    o_idx[qi] = idx;
-    o_d1[qi] = best;
-    o_d2[qi] = best2;
+    knn2_merge_query(parts, nshards, nq, qi, o_idx, o_d1, o_d2);
 }
 
 // src/ORBmatcher.cc:237 ((float)d1 < r*(float)d2), :487 (d1 <= d2*r, evaluated in float), with
@@ -208,17 +194,17 @@ int orbhip_matcher_create(orbhip_matcher** out, int device) {
 
 void orbhip_matcher_destroy(orbhip_matcher* m) {
     if (!m) return;
-    hipSetDevice(m->device);
-    if (m->stream) hipStreamSynchronize(m->stream);
-    if (m->d_part) hipFree(m->d_part);
-    if (m->d_stage) hipFree(m->d_stage);
-    if (m->d_gather) hipFree(m->d_gather);
-    if (m->d_work) hipFree(m->d_work);
-    if (m->d_topk) hipFree(m->d_topk);
-    if (m->d_err) hipFree(m->d_err);
-    if (m->ev0) hipEventDestroy(m->ev0);
-    if (m->ev1) hipEventDestroy(m->ev1);
-    if (m->stream) hipStreamDestroy(m->stream);
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->d_part) (void)hipFree(m->d_part);
+    if (m->d_stage) (void)hipFree(m->d_stage);
+    if (m->d_gather) (void)hipFree(m->d_gather);
+    if (m->d_work) (void)hipFree(m->d_work);
+    if (m->d_topk) (void)hipFree(m->d_topk);
+    if (m->d_err) (void)hipFree(m->d_err);
+    if (m->ev0) (void)hipEventDestroy(m->ev0);
+    if (m->ev1) (void)hipEventDestroy(m->ev1);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
 
@@ -315,16 +301,10 @@ static int knn2_launch(orbhip_matcher* m, const KnnPlan& plan, const uint8_t* d_
                        const uint8_t* d_t, int nt, ptrdiff_t t_pair_stride, int npairs, int idx_base, uint2* d_part,
                        int32_t* d_idx, int32_t* d_d1, int32_t* d_d2) {
     HIPCHK(hipEventRecord(m->ev0, m->stream));
-    // tiles of a chunk that go through the branch-free insertion before the vote path takes over
-    static const int sort_tiles = [] {
-        const char* e = getenv("ORBHIP_KNN_SORT_TILES");  // tuning experiments only
-        const int v = e ? atoi(e) : KMM_SORT_TILES_DEFAULT;
-        return std::max(0, std::min(v, (int)KMM_SORT_TILES_MAX));
-    }();
     if (m->scan_kernel == ORBHIP_SCAN_MATRIX)
-        hipLaunchKernelGGL(k_knn2_mm, dim3(plan.qblocks, plan.nchunks, npairs), dim3(256), 0, m->stream, (const uint32_t*)d_q,
-                           nq, (long long)(q_pair_stride / 4), (const uint32_t*)d_t, nt, (long long)(t_pair_stride / 4),
-                           plan.chunk_rows, plan.nchunks, idx_base, d_part, d_idx, d_d1, d_d2, sort_tiles);
+        orb_launch_knn2_matrix(m->stream, plan.qblocks, plan.nchunks, npairs, (const uint32_t*)d_q, nq,
+                               (long long)(q_pair_stride / 4), (const uint32_t*)d_t, nt, (long long)(t_pair_stride / 4),
+                               plan.chunk_rows, idx_base, d_part, d_idx, d_d1, d_d2);
     else
         hipLaunchKernelGGL(k_knn2, dim3(plan.qblocks, plan.nchunks, npairs), dim3(256), 0, m->stream, (const uint32_t*)d_q, nq,
                            (long long)(q_pair_stride / 4), (const uint32_t*)d_t, nt, (long long)(t_pair_stride / 4),
@@ -345,7 +325,7 @@ int orbhip_knn2_device(orbhip_matcher* m, const uint8_t* d_q, int nq, ptrdiff_t 
     HIPCHK(hipSetDevice(m->device));
     if (plan.part_bytes > m->part_bytes) {
         HIPCHK(hipStreamSynchronize(m->stream));
-        if (m->d_part) hipFree(m->d_part);
+        if (m->d_part) (void)hipFree(m->d_part);
         m->d_part = nullptr;
         m->part_bytes = 0;
         if (hipMalloc(&m->d_part, plan.part_bytes) != hipSuccess)
@@ -387,7 +367,7 @@ int orbhip_knn2(orbhip_matcher* m, const uint8_t* q, int nq, const uint8_t* t, i
     const size_t need = qb_al + tb_al + 3 * ob_al + 256;
     if (need > m->stage_bytes) {
         HIPCHK(hipStreamSynchronize(m->stream));
-        if (m->d_stage) hipFree(m->d_stage);
+        if (m->d_stage) (void)hipFree(m->d_stage);
         m->d_stage = nullptr;
         m->stage_bytes = 0;
         if (hipMalloc(&m->d_stage, need) != hipSuccess) return orb_fail(ORBHIP_ENOMEM, "hipMalloc of %zu bytes failed", need);
@@ -444,16 +424,16 @@ double orbhip_valu_rate(orbhip_matcher* m, int mode) {
     if (hipMalloc(&d, (size_t)blocks * 256 * 4) != hipSuccess) return 0.0;
     double best = 0.0;
     for (int rep = 0; rep < 4; rep++) {
-        hipEventRecord(m->ev0, m->stream);
+        (void)hipEventRecord(m->ev0, m->stream);
         hipLaunchKernelGGL(k_valu_rate, dim3(blocks), dim3(256), 0, m->stream, d, iters, mode, 12345u + rep);
-        hipEventRecord(m->ev1, m->stream);
+        (void)hipEventRecord(m->ev1, m->stream);
         if (hipStreamSynchronize(m->stream) != hipSuccess) break;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, m->ev0, m->ev1) != hipSuccess || ms <= 0.f) break;
         const double ops = (double)blocks * 256 * iters * 8;
         best = std::max(best, ops / (ms * 1e-3));
     }
-    hipFree(d);
+    (void)hipFree(d);
     return best;
 }
 

@@ -36,4 +36,11 @@ struct orbhip_matcher {
     int sm_count = 256;
 };
 
+// The matrix-core scan kernel lives in a translation unit of its own (knn2_matrix.hip): it is compiled with
+// floating-point options (IEEE mode off, no NaNs) that must not reach any other kernel.  Queues the kernel on
+// `stream`; grid (qblocks, nchunks, npairs), arguments as k_knn2's.
+void orb_launch_knn2_matrix(hipStream_t stream, int qblocks, int nchunks, int npairs, const uint32_t* d_q, int nq,
+                            long long q_pair_words, const uint32_t* d_t, int nt, long long t_pair_words, int chunk_rows,
+                            int idx_base, uint2* d_part, int32_t* d_idx, int32_t* d_d1, int32_t* d_d2);
+
 #endif

@@ -20,6 +20,7 @@
 
 #include "../../include/orbhip.h"
 #include "common.h"
+#include "knn2_merge.h"
 #include "matcher_internal.h"
 
 namespace {
@@ -163,7 +164,7 @@ int orbhip_knn2_sharded(orbhip_matcher* m, orbhip_comm* comm, const uint8_t* d_q
         // one shard and no communicator: the scan's result is the answer
         return orbhip_knn2_device(m, d_q, nq, 0, d_t_shard, nt_shard, 0, 1, idx_base, d_idx, d_d1, d_d2);
     }
-    const size_t rec = (size_t)3 * nq;  // int32 per rank: idx[nq], d1[nq], d2[nq]
+    const size_t rec = knn2_record_ints(nq);  // int32 per rank: idx[nq], d1[nq], d2[nq]
     const size_t need = rec * world * sizeof(int32_t);
     if (need > m->gather_bytes) {
         HIPCHK(hipStreamSynchronize(m->stream));
@@ -174,7 +175,7 @@ int orbhip_knn2_sharded(orbhip_matcher* m, orbhip_comm* comm, const uint8_t* d_q
         m->gather_bytes = need;
     }
     int32_t* all = (int32_t*)m->d_gather;
-    int32_t* mine = all + rec * rank;
+    int32_t* mine = all + knn2_slot_offset_ints(nq, rank);
     int rc = orbhip_knn2_device(m, d_q, nq, 0, d_t_shard, nt_shard, 0, 1, idx_base, mine, mine + nq, mine + 2 * (size_t)nq);
     if (rc) return rc;
     // in place: this rank's record already sits at its slot of the receive buffer

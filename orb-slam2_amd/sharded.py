@@ -17,6 +17,33 @@ def shard_range(n, rank, world):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+def gather_layout(nq, world, rank):
+    """orbhip_knn2_gather_layout: (int32 per record, int32 offset of rank's record, bytes of the receive buffer) of
+    the all-gather of orbhip_knn2_sharded."""
+    import ctypes as C
+    from . import _lib
+    rec, off, total = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    _lib.check(_lib.lib().orbhip_knn2_gather_layout(nq, world, rank, C.byref(rec), C.byref(off), C.byref(total)))
+    return rec.value, off.value, total.value
+
+
+def merge_host(parts, out=None):
+    """orbhip_knn2_merge_host: the ordered merge of orbhip_knn2_merge_device on records in host memory.
+    parts: int32 numpy array [nshards, 3, nq] (idx, d1, d2 per index-contiguous shard, ascending shard order).
+    Returns int32 [3, nq]."""
+    import ctypes as C
+    import numpy as np
+    from . import _lib
+    parts = np.ascontiguousarray(parts, dtype=np.int32)
+    nshards, three, nq = parts.shape
+    assert three == 3
+    if out is None:
+        out = np.empty((3, nq), np.int32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    _lib.check(_lib.lib().orbhip_knn2_merge_host(vp(parts), nshards, nq, vp(out[0]), vp(out[1]), vp(out[2])))
+    return out
+
+
 class Communicator:
     """orbhip_comm: one RCCL communicator (ncclComm_t) created inside liborbhip.so, one rank per process
     and GPU.  unique_id: the 128 bytes of orbhip_comm_unique_id() of ONE rank, handed to all ranks."""
@@ -88,7 +115,14 @@ def knn2_sharded(matcher, d_q, nq, d_t_shard, nt_shard, idx_base, parts_local, p
     world = 1
     if dist is not None and dist.is_initialized():
         world = dist.get_world_size(group)
-    if world > 1:
+    if world > 1 and parts_local.is_cuda and dist.get_backend(group) == "gloo":
+        # a transport that moves host memory only: the records go through the host and back (12 B per query and rank)
+        mine = parts_local.cpu()
+        gathered = mine.new_empty((world,) + tuple(mine.shape))
+        dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1), group=group)
+        parts_all.copy_(gathered)
+        _sync_current_stream(parts_all)
+    elif world > 1:
         dist.all_gather_into_tensor(parts_all.view(-1), parts_local.view(-1), group=group)
         _sync_current_stream(parts_all)
     else:

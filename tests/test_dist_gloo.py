@@ -1,7 +1,10 @@
-"""Multi-process partitioning logic on CPU (gloo, world_size 2): contiguous shard ranges and the
-all-gather + ordered merge of frame-vs-map matching.  The per-shard scan and the merge are done
-here by the oracle (no GPU in this test); what is covered is the sharding arithmetic, the
-collective's layout and that merging index-contiguous shards in rank order equals the serial scan."""
+"""Multi-process partitioning logic on CPU (gloo, world_size 2 and 3): contiguous shard ranges and the
+all-gather + ordered merge of frame-vs-map matching.  There is no GPU in this test, so the per-shard scan is
+done by the oracle; the records then travel through a real gloo all-gather in the layout the C entry point
+uses (orbhip_knn2_gather_layout) and are merged by the library's own merge function — the host twin
+orbhip_knn2_merge_host, compiled from the same source as the device kernel k_knn2_merge.  Covered: the sharding
+arithmetic, the collective's layout, and that merging index-contiguous shards in rank order equals the serial
+scan, including equal rows on both sides of a shard boundary."""
 import os
 import socket
 import sys
@@ -57,22 +60,9 @@ def _worker(rank, world, port, q_out):
             self.parts[2] = torch.from_numpy(d2)
 
         def merge_device(self, dparts, nshards, nq_, oi, o1, o2):
-            p = self.all.numpy()
-            best = np.full(nq_, 2147483647, np.int64)
-            best2 = best.copy()
-            idx = np.full(nq_, -1, np.int64)
-            for s in range(nshards):
-                i, d1, d2 = p[s]
-                ok = i >= 0
-                lt = ok & (d1 < best)
-                mid = ok & ~lt & (d1 < best2)
-                best2 = np.where(lt, best, np.where(mid, d1, best2))
-                idx = np.where(lt, i, idx)
-                best = np.where(lt, d1, best)
-                best2 = np.where(ok & (d2 < best2), d2, best2)
-            self.out[0] = torch.from_numpy(idx.astype(np.int32))
-            self.out[1] = torch.from_numpy(best.astype(np.int32))
-            self.out[2] = torch.from_numpy(best2.astype(np.int32))
+            # the library's merge (host twin of k_knn2_merge, same source) on the gathered records
+            merged = orb.sharded.merge_host(self.all.numpy())
+            self.out.copy_(torch.from_numpy(merged))
 
         def synchronize(self):
             pass
@@ -88,19 +78,42 @@ def _worker(rank, world, port, q_out):
     ridx, rd1, rd2 = orbref.knn2(q, t)
     ok = bool(np.array_equal(m.out[0].numpy(), ridx) and np.array_equal(m.out[1].numpy(), rd1)
               and np.array_equal(m.out[2].numpy(), rd2) and ridx[5] == 17)
+    # the gathered buffer holds rank r's record at the offset the C entry point uses for its in-place all-gather
+    rec, off, total = orb.sharded.gather_layout(nq, world, rank)
+    flat = m.all.numpy().reshape(-1)
+    ok = ok and rec == 3 * nq and total == 4 * rec * world and np.array_equal(flat[off:off + rec], m.parts.numpy().reshape(-1))
     q_out.put((rank, ok))
     dist.destroy_process_group()
 
 
-def test_sharded_knn_merge_two_ranks_gloo():
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_knn_merge_gloo(world):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]
     for p in procs:
         p.join(60)
-    assert sorted(res) == [(0, True), (1, True)]
+    assert sorted(res) == [(r, True) for r in range(world)]
+
+
+def test_merge_host_rule(orb):
+    """Known answers of the merge by hand: the earlier shard wins a tie on the best, a shard's second-best and a
+    later shard's best both compete for the second place, empty shards (idx -1) are skipped."""
+    big = 2147483647
+    parts = np.array([
+        # shard 0: idx, d1, d2          queries: 0      1      2      3     4
+        [[3, 3, -1, 7, 2], [10, 10, big, 30, 5], [20, 12, big, 31, 5]],
+        [[103, 104, 100, 105, -1], [10, 9, 40, 29, big], [11, 50, 41, 29, big]],
+    ], dtype=np.int32)
+    out = orb.sharded.merge_host(parts)
+    assert out[0].tolist() == [3, 104, 100, 105, 2]
+    assert out[1].tolist() == [10, 9, 40, 29, 5]
+    assert out[2].tolist() == [10, 10, 41, 29, 5]
+    for world in (1, 2, 8):
+        for rank in range(world):
+            assert orb.sharded.gather_layout(4000, world, rank) == (12000, 12000 * rank, 48000 * world)
