@@ -369,6 +369,10 @@ int orbhip_projection_from_sim3(const float* Scw, float fx, float fy, float cx, 
 #define ORBHIP_PROBES_KEYFRAME 1   /* SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist)  :1651-1690 */
 #define ORBHIP_PROBES_FRUSTUM 2    /* Frame::isInFrustum (src/Frame.cc:138-199) + SearchByProjection(F, vpMapPoints, th) :63-81 */
 #define ORBHIP_PROBES_FUSE 3       /* Fuse, both forms (:1054-1094, :1180-1223); SearchByProjection(pKF, Scw, ...) (:326-375) */
+#define ORBHIP_PROBES_WINDOW 4     /* SearchByProjection(F1, F2, windowSize, vpMapPointMatches2) (:545-566): radius = th =
+                                      windowSize, the source keypoint's octave the only level, no image test */
+#define ORBHIP_PROBES_SIM3 5       /* SearchBySim3, either direction (:1330-1375, :1415-1460); two cameras:
+                                      orbhip_build_probes_sim3_device */
 /* Replaces, for `batch` target frames, the lines of those methods between their pointer tests and their
  * GetFeaturesInArea call: frame f projects its d_npoints[f] map points (world positions d_pos, 3 floats each;
  * normals d_normal; GetMinDistanceInvariance / GetMaxDistanceInvariance in d_min_dist / d_max_dist; all indexed
@@ -386,6 +390,29 @@ int orbhip_build_probes_device(orbhip_matcher* m, int kind, const OrbProjection*
                                const float* d_min_dist, const float* d_max_dist, const OrbKeypoint* d_src_kp,
                                const uint8_t* d_skip, const int32_t* d_npoints, int batch, int probe_cap, float th,
                                float viewing_cos_limit, OrbProbe* d_probes);
+
+/* ORBHIP_PROBES_SIM3: one direction of ORBmatcher::SearchBySim3.  A map point of the source keyframe goes into that
+ * keyframe's camera (d_cams_from[f]: its pose) and from there through the similarity (d_cams_to[f]: Rcw = s*R,
+ * tcw = t, and the intrinsics the projection uses — orbhip_projection_sim3_pair builds both directions); depth,
+ * image and distance-range tests, predicted level and radius th * scale as in the reference; no viewing-angle test.
+ * The probes feed orbhip_best_in_radius_device.  Device pointers; asynchronous. */
+int orbhip_build_probes_sim3_device(orbhip_matcher* m, const OrbProjection* d_cams_from, const OrbProjection* d_cams_to,
+                                    OrbFrameBounds bounds, const float* d_scale_factors, int nlevels, const float* d_pos,
+                                    const float* d_min_dist, const float* d_max_dist, const uint8_t* d_skip,
+                                    const int32_t* d_npoints, int batch, int probe_cap, float th, OrbProbe* d_probes);
+/* The two similarities of ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:1290-1292) from s12, R12 (9 floats, row-major) and
+ * t12: *to2 carries sR21 = (1/s12) R12^T and t21 = -sR21 t12 (keyframe 1's points into camera 2), *to1 carries
+ * sR12 = s12 R12 and t12; both get the intrinsics (the reference projects both directions with pKF1's).  Host
+ * computation, rounded where cv::Mat arithmetic rounds. */
+int orbhip_projection_sim3_pair(float s12, const float* R12, const float* t12, float fx, float fy, float cx, float cy,
+                                OrbProjection* to2, OrbProjection* to1);
+/* Probes of ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th) (src/ORBmatcher.cc:52-81)
+ * from the fields Frame::isInFrustum left in each map point: proj_xy = (mTrackProjX, mTrackProjY), view_cos =
+ * mTrackViewCos, level = mnTrackScaleLevel; skip[i] != 0 stands for !mbTrackInView || isBad().  Radius =
+ * RadiusByViewingCos(view_cos) [* th if th != 1] * scale_factors[level], levels level-1 .. level.  Host computation
+ * (one multiply per point); a level outside [0, nlevels) is ORBHIP_EINVAL. */
+int orbhip_probes_from_tracked(int n, const float* proj_xy, const float* view_cos, const int32_t* level, const uint8_t* skip,
+                               float th, const float* scale_factors, int nlevels, OrbProbe* probes);
 
 /* The search the reference's Fuse and SearchBySim3 make per projected map point — "match to the most similar
  * keypoint in the radius" (ORBmatcher::Fuse src/ORBmatcher.cc:1096-1124 and :1225-1253, ORBmatcher::SearchBySim3
@@ -408,6 +435,40 @@ int orbhip_best_in_radius_device(orbhip_matcher* m, const OrbProbe* d_probes, co
 int orbhip_best_in_radius(orbhip_matcher* m, const OrbProbe* probes, const uint8_t* probe_desc, int nprobes,
                           const OrbKeypoint* kp2, const uint8_t* desc2, int n2, OrbFrameBounds bounds, int32_t* best_idx,
                           int32_t* best_dist);
+
+/* ---- Map points in, matches out: what the forwarding ORBmatcher methods call ---------------------------------
+ * The map points of one call as flat host arrays of n entries each: what the reference reads out of its MapPoint /
+ * Frame / KeyFrame objects between its pointer tests and its GetFeaturesInArea call.  Arrays a probe kind does not
+ * read (see orbhip_build_probes_device) may be NULL. */
+typedef struct OrbPointSet {
+    int32_t n;
+    const float* pos;          /* 3 per point: MapPoint::GetWorldPos() */
+    const float* normal;       /* 3 per point: MapPoint::GetNormal() */
+    const float* min_dist;     /* MapPoint::GetMinDistanceInvariance() */
+    const float* max_dist;     /* MapPoint::GetMaxDistanceInvariance() */
+    const OrbKeypoint* src_kp; /* the keypoint the point was observed at: octave and angle */
+    const uint8_t* skip;       /* != 0: the reference's pointer tests drop the point (NULL, isBad(), outlier, already found) */
+    const uint8_t* desc;       /* 32 per point: MapPoint::GetDescriptor(), or the source frame's descriptor row */
+} OrbPointSet;
+/* One call of a projection matcher for ONE target frame, host pointers, blocking: the points are projected with `cam`
+ * (orbhip_build_probes_device, kinds LAST_FRAME / KEYFRAME / FRUSTUM / FUSE / WINDOW), the probes stay on the device and
+ * feed orbhip_search_by_projection_device over the frame's grid.  match_of_feature (n2): the point assigned to each
+ * feature by this call or -1; *nmatches: the method's return value.  probes_out (may be NULL): the n probes, for
+ * inspection.  Replaces src/ORBmatcher.cc:297-418 (FUSE + ORBHIP_PROJ_BEST, th_dist TH_LOW), :530-605 (WINDOW +
+ * ORBHIP_PROJ_RATIO, TH_HIGH), :1518-1631 (LAST_FRAME + ORBHIP_PROJ_BEST, TH_HIGH), :1633-1757 (KEYFRAME +
+ * ORBHIP_PROJ_BEST, ORBdist). */
+int orbhip_project_and_search(orbhip_matcher* m, int kind, const OrbProjection* cam, const float* scale_factors, int nlevels,
+                              const OrbPointSet* pts, float th, float viewing_cos_limit, const OrbKeypoint* kp2,
+                              const uint8_t* desc2, int n2, OrbFrameBounds bounds, const uint8_t* taken, int rule, float nnratio,
+                              int th_dist, int check_orientation, int32_t* match_of_feature, int32_t* nmatches,
+                              OrbProbe* probes_out);
+/* The same for the independent search of Fuse (kind FUSE, cam_to NULL; src/ORBmatcher.cc:1054-1124, :1180-1253) and of
+ * one direction of SearchBySim3 (kind SIM3, cam = the source keyframe's pose, cam_to = the similarity; :1330-1404,
+ * :1415-1489): best_idx / best_dist per point as orbhip_best_in_radius_device returns them. */
+int orbhip_project_and_best_in_radius(orbhip_matcher* m, int kind, const OrbProjection* cam, const OrbProjection* cam_to,
+                                      const float* scale_factors, int nlevels, const OrbPointSet* pts, float th,
+                                      const OrbKeypoint* kp2, const uint8_t* desc2, int n2, OrbFrameBounds bounds,
+                                      int32_t* best_idx, int32_t* best_dist, OrbProbe* probes_out);
 
 /* Host-pointer forms of the two matchers for ONE frame pair (copy in, build F2's grid, match, copy
  * out; blocking) — what a forwarding ORBmatcher::SearchForInitialization / WindowSearch calls with

@@ -146,6 +146,9 @@ def lib():
     L.orbhip_projection_from_pose.argtypes = [vp, f32, f32, f32, f32, C.POINTER(OrbProjection)]
     L.orbhip_projection_from_sim3.argtypes = [vp, f32, f32, f32, f32, C.POINTER(OrbProjection)]
     L.orbhip_build_probes_device.argtypes = [vp, i32, vp, OrbFrameBounds, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, vp]
+    L.orbhip_build_probes_sim3_device.argtypes = [vp, vp, vp, OrbFrameBounds, vp, i32, vp, vp, vp, vp, vp, i32, i32, f32, vp]
+    L.orbhip_projection_sim3_pair.argtypes = [f32, vp, vp, f32, f32, f32, f32, C.POINTER(OrbProjection), C.POINTER(OrbProjection)]
+    L.orbhip_probes_from_tracked.argtypes = [i32, vp, vp, vp, vp, f32, vp, i32, vp]
     L.orbhip_best_in_radius_device.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, OrbFrameBounds, vp, vp]
     L.orbhip_best_in_radius.argtypes = [vp, vp, vp, i32, vp, vp, i32, OrbFrameBounds, vp, vp]
     L.orbhip_undistort_keypoints_device.argtypes = [vp, vp, vp, i32, i32, OrbCamera, vp]

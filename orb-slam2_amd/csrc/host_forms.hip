@@ -3,8 +3,10 @@
 // ORBmatcher::SearchForTriangulation (:863-1025),
 // MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:191-256), Frame::UndistortKeyPoints
 // (src/Frame.cc:290-320) and the per-feature vocabulary descent behind Frame::ComputeBoW (:281-288).
-// Each copies its arguments into a staging arena of the handle, runs the device entry point on the
-// matcher's stream and copies the results back (blocking).  No arithmetic of the path happens here.
+// and the two "map points in, matches out" forms behind the projection matchers, Fuse and SearchBySim3
+// (orbhip_project_and_search, orbhip_project_and_best_in_radius: probes are built and consumed on the
+// device).  Each copies its arguments into a staging arena of the handle, runs the device entry points on
+// the matcher's stream and copies the results back (blocking).  No arithmetic of the path happens here.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -61,9 +63,138 @@ int check_fv(const FvHost& fv, int n, const char* which) {
     return ORBHIP_OK;
 }
 
+// Stages one target frame and one point set, builds the frame's grid and the probes of the points on the device.
+struct ProjectStage {
+    char* b = nullptr;
+    size_t o_pr, o_pd, o_kp, o_d, o_t, o_n, o_cs, o_ci, o_a, o_b, o_scalar;
+    int cap, pcap;
+};
+
+int project_stage(orbhip_matcher* m, int kind, const OrbProjection* cam, const OrbProjection* cam_to, const float* scale_factors,
+                  int nlevels, const OrbPointSet* pts, float th, float viewing_cos_limit, const OrbKeypoint* kp2,
+                  const uint8_t* desc2, int n2, OrbFrameBounds bounds, const uint8_t* taken, size_t out_a_bytes_per,
+                  bool out_per_probe, ProjectStage& st) {
+    if (!m) return orb_fail(ORBHIP_EINVAL, "null matcher");
+    if (!pts || !cam || !scale_factors) return orb_fail(ORBHIP_EINVAL, "null argument");
+    const int np = pts->n;
+    if (np < 0 || n2 < 0 || nlevels < 1 || nlevels > 64) return orb_fail(ORBHIP_EINVAL, "bad size");
+    if (np && (!pts->pos || !pts->desc)) return orb_fail(ORBHIP_EINVAL, "a point set needs positions and descriptors");
+    if (n2 && (!kp2 || !desc2)) return orb_fail(ORBHIP_EINVAL, "null buffer");
+    if ((kind == ORBHIP_PROBES_SIM3) != (cam_to != nullptr))
+        return orb_fail(ORBHIP_EINVAL, "a second camera goes with ORBHIP_PROBES_SIM3 and with no other kind");
+    const int cap = std::max(1, n2), pcap = std::max(1, np);
+    if (cap > ORBHIP_FRAME_MAX_KEYPOINTS) return orb_fail(ORBHIP_ECAP, "%d features > %d per frame", cap, ORBHIP_FRAME_MAX_KEYPOINTS);
+    HIPCHK(hipSetDevice(m->device));
+    Arena a;
+    st.cap = cap;
+    st.pcap = pcap;
+    st.o_pr = a.take(sizeof(OrbProbe) * pcap);
+    st.o_pd = a.take(32 * (size_t)pcap);
+    st.o_kp = a.take(sizeof(OrbKeypoint) * cap);
+    st.o_d = a.take(32 * (size_t)cap);
+    st.o_t = a.take(cap);
+    st.o_n = a.take(sizeof(int32_t) * 2);
+    st.o_cs = a.take(sizeof(int32_t) * (ORBHIP_FRAME_GRID_CELLS + 1));
+    st.o_ci = a.take(sizeof(int32_t) * cap);
+    st.o_a = a.take(out_a_bytes_per * (out_per_probe ? pcap : cap));
+    st.o_b = a.take(sizeof(int32_t) * (out_per_probe ? pcap : 1));
+    const size_t o_cam = a.take(sizeof(OrbProjection) * 2), o_sf = a.take(sizeof(float) * nlevels);
+    const size_t o_pos = a.take(sizeof(float) * 3 * pcap), o_nrm = a.take(sizeof(float) * 3 * pcap);
+    const size_t o_min = a.take(sizeof(float) * pcap), o_max = a.take(sizeof(float) * pcap);
+    const size_t o_src = a.take(sizeof(OrbKeypoint) * pcap), o_skip = a.take(pcap);
+    int rc = reserve_stage(m, a.off);
+    if (rc) return rc;
+    char* b = st.b = (char*)m->d_stage;
+    const int32_t n[2] = {np, n2};
+    OrbProjection cams[2] = {*cam, cam_to ? *cam_to : *cam};
+    HIPCHK(hipMemcpyAsync(b + st.o_n, n, sizeof(n), hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(b + o_cam, cams, sizeof(cams), hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(b + o_sf, scale_factors, sizeof(float) * nlevels, hipMemcpyHostToDevice, m->stream));
+    if (np) {
+        HIPCHK(hipMemcpyAsync(b + o_pos, pts->pos, sizeof(float) * 3 * np, hipMemcpyHostToDevice, m->stream));
+        HIPCHK(hipMemcpyAsync(b + st.o_pd, pts->desc, 32 * (size_t)np, hipMemcpyHostToDevice, m->stream));
+        if (pts->normal) HIPCHK(hipMemcpyAsync(b + o_nrm, pts->normal, sizeof(float) * 3 * np, hipMemcpyHostToDevice, m->stream));
+        if (pts->min_dist) HIPCHK(hipMemcpyAsync(b + o_min, pts->min_dist, sizeof(float) * np, hipMemcpyHostToDevice, m->stream));
+        if (pts->max_dist) HIPCHK(hipMemcpyAsync(b + o_max, pts->max_dist, sizeof(float) * np, hipMemcpyHostToDevice, m->stream));
+        if (pts->src_kp) HIPCHK(hipMemcpyAsync(b + o_src, pts->src_kp, sizeof(OrbKeypoint) * np, hipMemcpyHostToDevice, m->stream));
+        if (pts->skip) HIPCHK(hipMemcpyAsync(b + o_skip, pts->skip, np, hipMemcpyHostToDevice, m->stream));
+    }
+    if (n2) {
+        HIPCHK(hipMemcpyAsync(b + st.o_kp, kp2, sizeof(OrbKeypoint) * n2, hipMemcpyHostToDevice, m->stream));
+        HIPCHK(hipMemcpyAsync(b + st.o_d, desc2, 32 * (size_t)n2, hipMemcpyHostToDevice, m->stream));
+        if (taken) HIPCHK(hipMemcpyAsync(b + st.o_t, taken, n2, hipMemcpyHostToDevice, m->stream));
+    }
+    HIPCHK(hipStreamSynchronize(m->stream));  // n[] and cams[] live on this stack frame
+    if ((rc = orbhip_frame_grid_device(m, (const OrbKeypoint*)(b + st.o_kp), (const int32_t*)(b + st.o_n) + 1, 1, cap, bounds,
+                                       (int32_t*)(b + st.o_cs), (int32_t*)(b + st.o_ci))))
+        return rc;
+    const OrbProjection* d_cams = (const OrbProjection*)(b + o_cam);
+    const float* d_sf = (const float*)(b + o_sf);
+    const float* d_pos = (const float*)(b + o_pos);
+    const float* d_min = pts->min_dist ? (const float*)(b + o_min) : nullptr;
+    const float* d_max = pts->max_dist ? (const float*)(b + o_max) : nullptr;
+    const uint8_t* d_skip = pts->skip ? (const uint8_t*)(b + o_skip) : nullptr;
+    if (kind == ORBHIP_PROBES_SIM3)
+        return orbhip_build_probes_sim3_device(m, d_cams, d_cams + 1, bounds, d_sf, nlevels, d_pos, d_min, d_max, d_skip,
+                                               (const int32_t*)(b + st.o_n), 1, pcap, th, (OrbProbe*)(b + st.o_pr));
+    return orbhip_build_probes_device(m, kind, d_cams, bounds, d_sf, nlevels, d_pos, pts->normal ? (const float*)(b + o_nrm) : nullptr,
+                                      d_min, d_max, pts->src_kp ? (const OrbKeypoint*)(b + o_src) : nullptr, d_skip,
+                                      (const int32_t*)(b + st.o_n), 1, pcap, th, viewing_cos_limit, (OrbProbe*)(b + st.o_pr));
+}
+
 }  // namespace
 
 extern "C" {
+
+int orbhip_project_and_search(orbhip_matcher* m, int kind, const OrbProjection* cam, const float* scale_factors, int nlevels,
+                              const OrbPointSet* pts, float th, float viewing_cos_limit, const OrbKeypoint* kp2,
+                              const uint8_t* desc2, int n2, OrbFrameBounds bounds, const uint8_t* taken, int rule, float nnratio,
+                              int th_dist, int check_orientation, int32_t* match_of_feature, int32_t* nmatches,
+                              OrbProbe* probes_out) {
+    if (!nmatches || (n2 > 0 && !match_of_feature)) return orb_fail(ORBHIP_EINVAL, "null buffer");
+    if (kind == ORBHIP_PROBES_SIM3) return orb_fail(ORBHIP_EINVAL, "ORBHIP_PROBES_SIM3 feeds orbhip_project_and_best_in_radius");
+    if (pts && pts->n > ORBHIP_MAX_PROBES) return orb_fail(ORBHIP_ECAP, "%d probes > %d", pts->n, ORBHIP_MAX_PROBES);
+    ProjectStage st;
+    int rc = project_stage(m, kind, cam, nullptr, scale_factors, nlevels, pts, th, viewing_cos_limit, kp2, desc2, n2, bounds, taken,
+                           sizeof(int32_t), false, st);
+    if (rc) return rc;
+    char* b = st.b;
+    if ((rc = orbhip_search_by_projection_device(
+             m, (const OrbProbe*)(b + st.o_pr), (const uint8_t*)(b + st.o_pd), (const int32_t*)(b + st.o_n), st.pcap,
+             (const OrbKeypoint*)(b + st.o_kp), (const uint8_t*)(b + st.o_d), (const int32_t*)(b + st.o_n) + 1,
+             (const int32_t*)(b + st.o_cs), (const int32_t*)(b + st.o_ci), 1, st.cap, bounds, taken ? (const uint8_t*)(b + st.o_t) : nullptr,
+             rule, nnratio, th_dist, check_orientation, (int32_t*)(b + st.o_a), (int32_t*)(b + st.o_b))))
+        return rc;
+    if (n2) HIPCHK(hipMemcpyAsync(match_of_feature, b + st.o_a, sizeof(int32_t) * n2, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(nmatches, b + st.o_b, sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+    if (probes_out && pts->n) HIPCHK(hipMemcpyAsync(probes_out, b + st.o_pr, sizeof(OrbProbe) * pts->n, hipMemcpyDeviceToHost, m->stream));
+    return orbhip_matcher_synchronize(m);
+}
+
+int orbhip_project_and_best_in_radius(orbhip_matcher* m, int kind, const OrbProjection* cam, const OrbProjection* cam_to,
+                                      const float* scale_factors, int nlevels, const OrbPointSet* pts, float th,
+                                      const OrbKeypoint* kp2, const uint8_t* desc2, int n2, OrbFrameBounds bounds,
+                                      int32_t* best_idx, int32_t* best_dist, OrbProbe* probes_out) {
+    if (pts && pts->n > 0 && (!best_idx || !best_dist)) return orb_fail(ORBHIP_EINVAL, "null buffer");
+    if (kind != ORBHIP_PROBES_FUSE && kind != ORBHIP_PROBES_SIM3)
+        return orb_fail(ORBHIP_EINVAL, "the independent search goes with ORBHIP_PROBES_FUSE or ORBHIP_PROBES_SIM3");
+    if (pts && pts->n == 0) return ORBHIP_OK;
+    ProjectStage st;
+    int rc = project_stage(m, kind, cam, cam_to, scale_factors, nlevels, pts, th, 0.f, kp2, desc2, n2, bounds, nullptr, sizeof(int32_t),
+                           true, st);
+    if (rc) return rc;
+    char* b = st.b;
+    if ((rc = orbhip_best_in_radius_device(m, (const OrbProbe*)(b + st.o_pr), (const uint8_t*)(b + st.o_pd),
+                                           (const int32_t*)(b + st.o_n), st.pcap, (const OrbKeypoint*)(b + st.o_kp),
+                                           (const uint8_t*)(b + st.o_d), (const int32_t*)(b + st.o_cs),
+                                           (const int32_t*)(b + st.o_ci), 1, st.cap, bounds, (int32_t*)(b + st.o_a),
+                                           (int32_t*)(b + st.o_b))))
+        return rc;
+    HIPCHK(hipMemcpyAsync(best_idx, b + st.o_a, sizeof(int32_t) * pts->n, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipMemcpyAsync(best_dist, b + st.o_b, sizeof(int32_t) * pts->n, hipMemcpyDeviceToHost, m->stream));
+    if (probes_out) HIPCHK(hipMemcpyAsync(probes_out, b + st.o_pr, sizeof(OrbProbe) * pts->n, hipMemcpyDeviceToHost, m->stream));
+    return orbhip_matcher_synchronize(m);
+}
 
 int orbhip_search_by_bow(orbhip_matcher* m, const OrbKeypoint* kp1, const uint8_t* desc1, int n1, const uint8_t* valid1,
                          const int32_t* fv1_nodes, const int32_t* fv1_start, const int32_t* fv1_feat, int fv1_count,

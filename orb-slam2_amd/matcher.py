@@ -193,7 +193,7 @@ class ORBmatcher:
         self._end()
         return nm, out
 
-    PROBES_LAST_FRAME, PROBES_KEYFRAME, PROBES_FRUSTUM, PROBES_FUSE = 0, 1, 2, 3
+    PROBES_LAST_FRAME, PROBES_KEYFRAME, PROBES_FRUSTUM, PROBES_FUSE, PROBES_WINDOW, PROBES_SIM3 = 0, 1, 2, 3, 4, 5
 
     @staticmethod
     def projections(poses, K, sim3=False):
@@ -208,6 +208,53 @@ class ORBmatcher:
             _lib.check(f(_p(t), float(K[0]), float(K[1]), float(K[2]), float(K[3]), C.byref(arr[i])))
         raw = np.frombuffer(bytes(arr), np.uint8).reshape(max(len(poses), 1), C.sizeof(_lib.OrbProjection))
         return torch.from_numpy(raw.copy()).cuda()
+
+    @staticmethod
+    def sim3_projections(s12, R12, t12, K):
+        """orbhip_projection_sim3_pair: the two similarities of SearchBySim3 (src/ORBmatcher.cc:1290-1292) as
+        OrbProjection records on the device, (to2, to1): to2 moves keyframe 1's points into camera 2 (sR21, t21), to1
+        the other way (sR12, t12); K = (fx, fy, cx, cy) of keyframe 1."""
+        import torch
+        L = _lib.lib()
+        to2, to1 = _lib.OrbProjection(), _lib.OrbProjection()
+        R = np.ascontiguousarray(R12, np.float32).reshape(9)
+        t = np.ascontiguousarray(t12, np.float32).reshape(3)
+        _lib.check(L.orbhip_projection_sim3_pair(float(s12), _p(R), _p(t), float(K[0]), float(K[1]), float(K[2]), float(K[3]),
+                                                 C.byref(to2), C.byref(to1)))
+        rec = lambda a: torch.from_numpy(np.frombuffer(bytes(a), np.uint8).reshape(1, C.sizeof(_lib.OrbProjection)).copy()).cuda()  # noqa: E731
+        return rec(to2), rec(to1)
+
+    def BuildProbesSim3(self, cams_from, cams_to, bounds, scale_factors, pos, npoints, th, min_dist, max_dist, skip=None):
+        """One direction of SearchBySim3 (src/ORBmatcher.cc:1330-1375, :1415-1460) on the device: the points go through
+        their own keyframe's pose (cams_from: projections()) and then through the similarity (cams_to:
+        sim3_projections()).  Other arguments and the result as for BuildProbes."""
+        import torch
+        B, pcap = int(pos.shape[0]), int(pos.shape[1])
+        assert pos.is_cuda and pos.dtype == torch.float32 and pos.is_contiguous() and pos.shape[2] == 3
+        sf = scale_factors if torch.is_tensor(scale_factors) else torch.from_numpy(np.ascontiguousarray(scale_factors, np.float32)).cuda()
+        probes = torch.empty((B, max(pcap, 1), 32), dtype=torch.uint8, device=pos.device)
+        self._begin()
+        _lib.check(self._L.orbhip_build_probes_sim3_device(
+            self._h, cams_from.data_ptr(), cams_to.data_ptr(), _lib.OrbFrameBounds(*map(int, bounds)), sf.data_ptr(), int(sf.numel()),
+            pos.data_ptr(), min_dist.data_ptr(), max_dist.data_ptr(), 0 if skip is None else skip.data_ptr(), npoints.data_ptr(), B,
+            max(pcap, 1), float(th), probes.data_ptr()))
+        self._end()
+        return probes
+
+    @staticmethod
+    def probes_from_tracked(proj_xy, view_cos, level, skip, th, scale_factors):
+        """orbhip_probes_from_tracked (host): the probes of SearchByProjection(F, vpMapPoints, th) from the fields
+        Frame::isInFrustum left in the map points.  numpy in, PROBE_DTYPE array out."""
+        from . import PROBE_DTYPE
+        n = len(level)
+        xy = np.ascontiguousarray(proj_xy, np.float32).reshape(-1)
+        vc = np.ascontiguousarray(view_cos, np.float32)
+        lv = np.ascontiguousarray(level, np.int32)
+        sk = np.ascontiguousarray(skip, np.uint8)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        out = np.zeros(max(n, 1), PROBE_DTYPE)
+        _lib.check(_lib.lib().orbhip_probes_from_tracked(n, _p(xy), _p(vc), _p(lv), _p(sk), float(th), _p(sf), len(sf), _p(out)))
+        return out[:n]
 
     def BuildProbes(self, kind, cams, bounds, scale_factors, pos, npoints, th, normal=None, min_dist=None, max_dist=None,
                     src_kp=None, skip=None, viewing_cos_limit=0.5):

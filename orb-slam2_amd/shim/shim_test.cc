@@ -13,138 +13,19 @@
 #include <vector>
 
 #include "ORBextractor.h"
-#include "ORBmatcher_accel.h"
+#include "ORBmatcher.h"
+#include "FrameSteps.h"
+#include "KeyFrame.h"
+#include "MapPoint.h"
+#include "../../include/orbhip.h"
 
-// Stand-ins with the members of ORB_SLAM::Frame / KeyFrame / MapPoint and of the DBoW2 containers that the
-// forwarding bodies touch (include/Frame.h, include/KeyFrame.h, include/MapPoint.h,
-// Thirdparty/DBoW2/DBoW2/{BowVector,FeatureVector}.h).
-namespace DBoW2 {
-enum LNorm { L1, L2 };
-struct BowVector : std::map<unsigned int, double> {
-    void addWeight(unsigned int id, double v) {
-        iterator vit = lower_bound(id);
-        if (vit != end() && !(key_comp()(id, vit->first)))
-            vit->second += v;
-        else
-            insert(vit, value_type(id, v));
-    }
-    void normalize(LNorm) {  // L1
-        double norm = 0.0;
-        for (iterator it = begin(); it != end(); ++it) norm += it->second < 0 ? -it->second : it->second;
-        if (norm > 0.0)
-            for (iterator it = begin(); it != end(); ++it) it->second /= norm;
-    }
-};
-struct FeatureVector : std::map<unsigned int, std::vector<unsigned int> > {
-    void addFeature(unsigned int id, unsigned int i_feature) {
-        iterator vit = lower_bound(id);
-        if (vit != end() && vit->first == id)
-            vit->second.push_back(i_feature);
-        else {
-            vit = insert(vit, value_type(id, std::vector<unsigned int>()));
-            vit->second.push_back(i_feature);
-        }
-    }
-};
-}  // namespace DBoW2
-
-struct FakeKeyFrame;
-struct FakeMapPoint {
-    bool bad;
-    std::map<FakeKeyFrame*, size_t> mObservations;
-    bool IsInKeyFrame(FakeKeyFrame* pKF) { return mObservations.count(pKF) != 0; }
-    int GetIndexInKeyFrame(FakeKeyFrame* pKF) { return mObservations.count(pKF) ? (int)mObservations[pKF] : -1; }
-    void AddObservation(FakeKeyFrame* pKF, size_t idx) {  // src/MapPoint.cc:72-85 without the counters
-        if (mObservations.count(pKF)) return;
-        mObservations[pKF] = idx;
-    }
-    inline void Replace(FakeMapPoint* pMP);  // src/MapPoint.cc:130-164 without the descriptor update and the map
-    // tracking fields written by Frame::isInFrustum (include/MapPoint.h)
-    bool mbTrackInView;
-    int mnTrackScaleLevel;
-    float mTrackViewCos, mTrackProjX, mTrackProjY;
-    cv::Mat descriptor, pos, normal;
-    float minDist, maxDist;
-    FakeMapPoint()
-        : bad(false), mbTrackInView(false), mnTrackScaleLevel(0), mTrackViewCos(1.f), mTrackProjX(0.f), mTrackProjY(0.f),
-          minDist(0.f), maxDist(0.f) {}
-    bool isBad() const { return bad; }
-    cv::Mat GetDescriptor() const { return descriptor; }
-    cv::Mat GetWorldPos() const { return pos.clone(); }
-    cv::Mat GetNormal() const { return normal.clone(); }
-    float GetMinDistanceInvariance() const { return minDist; }
-    float GetMaxDistanceInvariance() const { return maxDist; }
-};
-struct FakeFrame {
-    std::vector<cv::KeyPoint> mvKeys, mvKeysUn;
-    cv::Mat mDescriptors, mTcw, mK, mDistCoef;
-    std::vector<FakeMapPoint*> mvpMapPoints;
-    std::vector<bool> mvbOutlier;
-    std::vector<float> mvScaleFactors;
-    int mnScaleLevels;
-    DBoW2::BowVector mBowVec;
-    DBoW2::FeatureVector mFeatVec;
-    static int mnMinX, mnMinY, mnMaxX, mnMaxY;
-    static float fx, fy, cx, cy;
-};
-int FakeFrame::mnMinX, FakeFrame::mnMinY, FakeFrame::mnMaxX, FakeFrame::mnMaxY;
-float FakeFrame::fx, FakeFrame::fy, FakeFrame::cx, FakeFrame::cy;
-struct FakeKeyFrame {
-    float fx, fy, cx, cy;
-    std::vector<cv::KeyPoint> keysUn;
-    cv::Mat descriptors;
-    std::vector<FakeMapPoint*> mapPoints;
-    std::vector<float> scaleFactors;
-    DBoW2::FeatureVector featVec;
-    int GetScaleLevels() const { return (int)scaleFactors.size(); }
-    std::vector<float> GetScaleFactors() const { return scaleFactors; }
-    float GetScaleFactor(int nLevel = 1) const { return scaleFactors[nLevel]; }
-    bool IsInImage(const float& x, const float& y) const {
-        return x >= FakeFrame::mnMinX && x < FakeFrame::mnMaxX && y >= FakeFrame::mnMinY && y < FakeFrame::mnMaxY;
-    }
-    std::vector<cv::KeyPoint> GetKeyPointsUn() const { return keysUn; }
-    cv::KeyPoint GetKeyPointUn(const size_t& idx) const { return keysUn[idx]; }
-    cv::Mat GetDescriptors() { return descriptors.clone(); }
-    std::vector<FakeMapPoint*> GetMapPointMatches() { return mapPoints; }
-    DBoW2::FeatureVector GetFeatureVector() { return featVec; }
-    std::vector<float> levelSigma2;
-    float GetSigma2(int nLevel = 1) const { return levelSigma2[nLevel]; }
-    // pose, as KeyFrame::SetPose keeps it (src/KeyFrame.cc:102-109)
-    cv::Mat Rcw, tcw, Ow;
-    void SetPose(const cv::Mat& Tcw) {
-        Rcw = Tcw.rowRange(0, 3).colRange(0, 3).clone();
-        tcw = Tcw.rowRange(0, 3).col(3).clone();
-        Ow = -Rcw.t() * tcw;
-    }
-    cv::Mat GetRotation() { return Rcw.clone(); }
-    cv::Mat GetTranslation() { return tcw.clone(); }
-    cv::Mat GetCameraCenter() { return Ow.clone(); }
-    FakeMapPoint* GetMapPoint(const size_t& idx) { return mapPoints[idx]; }
-    void AddMapPoint(FakeMapPoint* pMP, const size_t& idx) { mapPoints[idx] = pMP; }
-    void ReplaceMapPointMatch(const size_t& idx, FakeMapPoint* pMP) { mapPoints[idx] = pMP; }
-    void EraseMapPointMatch(const size_t& idx) { mapPoints[idx] = 0; }
-    std::set<FakeMapPoint*> GetMapPoints() {
-        std::set<FakeMapPoint*> s;
-        for (size_t i = 0; i < mapPoints.size(); i++)
-            if (mapPoints[i]) s.insert(mapPoints[i]);
-        return s;
-    }
-};
-inline void FakeMapPoint::Replace(FakeMapPoint* pMP) {
-    if (pMP == this) return;
-    std::map<FakeKeyFrame*, size_t> obs = mObservations;
-    mObservations.clear();
-    bad = true;
-    for (std::map<FakeKeyFrame*, size_t>::iterator mit = obs.begin(), mend = obs.end(); mit != mend; mit++) {
-        FakeKeyFrame* pKF = mit->first;
-        if (!pMP->IsInKeyFrame(pKF)) {
-            pKF->ReplaceMapPointMatch(mit->second, pMP);
-            pMP->AddObservation(pKF, mit->second);
-        } else {
-            pKF->EraseMapPointMatch(mit->second);
-        }
-    }
-}
+// Frame, KeyFrame and MapPoint are the stand-ins of shim/standin (the reference's names and accessors over plain
+// members); the static members of Frame are defined here.
+using ORB_SLAM::Frame;
+using ORB_SLAM::KeyFrame;
+using ORB_SLAM::MapPoint;
+int Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY;
+float Frame::fx, Frame::fy, Frame::cx, Frame::cy;
 
 // shim_test --latency <in.raw> <rows> <cols> <nfeatures> <calls>: the call of src/Frame.cc:61 repeated on one
 // image, one frame per call as the tracking thread makes it; prints the median, 10th and 90th percentile of the
@@ -175,7 +56,7 @@ static int latency_mode(int argc, char** argv) {
 }
 
 
-// shim_test --matchers <mode> <in.bin> <out.bin>: one forwarding body of shim/ORBmatcher_accel.h on inputs a
+// shim_test --matchers <mode> <in.bin> <out.bin>: one forwarding body of shim/ORBmatcher.cc on inputs a
 // test wrote, results back for comparison with the oracle.  Both files are sequences of blobs, each an int32
 // byte count followed by the bytes.
 typedef std::vector<std::vector<unsigned char> > Blobs;
@@ -230,7 +111,7 @@ static int matchers_mode(int argc, char** argv) {
     if (!read_blobs(argv[3], in)) return 3;
     FILE* out = fopen(argv[4], "wb");
     if (!out) return 3;
-    static FakeMapPoint pre;  // the map point a feature holds on entry
+    static MapPoint pre;  // the map point a feature holds on entry
     if (mode == "sim3" || mode == "frames" || mode == "last" || mode == "keyframe") {
         // blobs: 0 int params {th, window, orbdist, check_ori}, 1 float params {fx, fy, cx, cy, ratio, th}, 2 bounds,
         // 3 target keypoints, 4 target descriptors, 5 taken, 6 pose (4x4), 7 scale factors, 8 skip kind per point
@@ -239,14 +120,14 @@ static int matchers_mode(int argc, char** argv) {
         const int* ip = as<int>(in[0]);
         const float* fp = as<float>(in[1]);
         const int* bd = as<int>(in[2]);
-        FakeFrame::mnMinX = bd[0]; FakeFrame::mnMinY = bd[1]; FakeFrame::mnMaxX = bd[2]; FakeFrame::mnMaxY = bd[3];
-        FakeFrame::fx = fp[0]; FakeFrame::fy = fp[1]; FakeFrame::cx = fp[2]; FakeFrame::cy = fp[3];
-        ORB_SLAM::ORBmatcherAccel matcher(fp[4], ip[3] != 0);
-        FakeFrame T;  // the target frame
+        Frame::mnMinX = bd[0]; Frame::mnMinY = bd[1]; Frame::mnMaxX = bd[2]; Frame::mnMaxY = bd[3];
+        Frame::fx = fp[0]; Frame::fy = fp[1]; Frame::cx = fp[2]; Frame::cy = fp[3];
+        ORB_SLAM::ORBmatcher matcher(fp[4], ip[3] != 0);
+        Frame T;  // the target frame
         T.mvKeysUn = T.mvKeys = keypoints(in[3]);
         T.mDescriptors = mat_desc(in[4]);
         const int n = (int)T.mvKeysUn.size();
-        T.mvpMapPoints.assign(n, (FakeMapPoint*)0);
+        T.mvpMapPoints.assign(n, (MapPoint*)0);
         for (int i = 0; i < n; i++)
             if (in[5][i]) T.mvpMapPoints[i] = &pre;
         T.mTcw = mat_f32(4, 4, as<float>(in[6]));
@@ -254,67 +135,67 @@ static int matchers_mode(int argc, char** argv) {
         T.mvScaleFactors.assign(as<float>(in[7]), as<float>(in[7]) + nlev);
         T.mnScaleLevels = nlev;
         const int npts = (int)in[8].size();
-        std::vector<FakeMapPoint> pts(npts);
-        std::vector<FakeMapPoint*> vp(npts);
-        std::set<FakeMapPoint*> found;
+        std::vector<MapPoint> pts(npts);
+        std::vector<MapPoint*> vp(npts);
+        std::set<MapPoint*> found;
         cv::Mat pdesc = mat_desc(in[13]);
         for (int i = 0; i < npts; i++) {
-            pts[i].bad = in[8][i] == 2;
-            pts[i].pos = mat_f32(3, 1, as<float>(in[9]) + 3 * i);
-            pts[i].normal = mat_f32(3, 1, as<float>(in[10]) + 3 * i);
-            pts[i].minDist = as<float>(in[11])[i];
-            pts[i].maxDist = as<float>(in[12])[i];
-            pts[i].descriptor = pdesc.row(i);
-            vp[i] = in[8][i] == 1 ? (FakeMapPoint*)0 : &pts[i];
+            pts[i].mbBad = in[8][i] == 2;
+            pts[i].mWorldPos = mat_f32(3, 1, as<float>(in[9]) + 3 * i);
+            pts[i].mNormalVector = mat_f32(3, 1, as<float>(in[10]) + 3 * i);
+            pts[i].mfMinDistance = as<float>(in[11])[i];
+            pts[i].mfMaxDistance = as<float>(in[12])[i];
+            pts[i].mDescriptor = pdesc.row(i);
+            vp[i] = in[8][i] == 1 ? (MapPoint*)0 : &pts[i];
             if (in[8][i] == 3) found.insert(&pts[i]);
         }
         int nmatches = -1;
-        std::vector<FakeMapPoint*> result;
+        std::vector<MapPoint*> result;
         if (mode == "sim3") {
-            FakeKeyFrame KF;
+            KeyFrame KF;
             KF.fx = fp[0]; KF.fy = fp[1]; KF.cx = fp[2]; KF.cy = fp[3];
-            KF.keysUn = T.mvKeysUn;
-            KF.descriptors = T.mDescriptors;
-            KF.scaleFactors = T.mvScaleFactors;
+            KF.mvKeysUn = T.mvKeysUn;
+            KF.mDescriptors = T.mDescriptors;
+            KF.mvScaleFactors = T.mvScaleFactors;
             // "already found" points of this overload sit in vpMatched on entry: give each one a feature that is taken
             result = T.mvpMapPoints;
-            std::set<FakeMapPoint*>::iterator it = found.begin();
+            std::set<MapPoint*>::iterator it = found.begin();
             for (int i = 0; i < n && it != found.end(); i++)
                 if (result[i] == &pre) result[i] = *it++;
             for (int i = 0; i < npts; i++)
                 if (!vp[i]) vp[i] = &pre;  // this overload has no NULL test: a NULL point is modelled as already found
-            nmatches = matcher.SearchByProjection<FakeFrame>(&KF, T.mTcw, vp, result, ip[0]);
+            nmatches = matcher.SearchByProjection(&KF, T.mTcw, vp, result, ip[0]);
         } else if (mode == "frames") {
-            FakeFrame F1;
+            Frame F1;
             F1.mvKeysUn = keypoints(in[14]);
             F1.mDescriptors = pdesc;
             F1.mvpMapPoints = vp;
             // an "already found" point is one F2 already holds
-            std::set<FakeMapPoint*>::iterator it = found.begin();
+            std::set<MapPoint*>::iterator it = found.begin();
             for (int i = 0; i < n && it != found.end(); i++)
                 if (T.mvpMapPoints[i] == &pre) T.mvpMapPoints[i] = *it++;
             nmatches = matcher.SearchByProjection(F1, T, ip[1], result);
         } else if (mode == "last") {
-            FakeFrame L;
+            Frame L;
             L.mvKeys = L.mvKeysUn = keypoints(in[14]);
             L.mDescriptors = pdesc;
             L.mvpMapPoints = vp;
             L.mvbOutlier.assign(npts, false);
             for (int i = 0; i < npts; i++)
                 if (in[8][i] >= 2) L.mvbOutlier[i] = true;  // kinds 2 and 3 stand for outliers here
-            for (int i = 0; i < npts; i++) pts[i].bad = false;
-            nmatches = matcher.SearchByProjection(T, (const FakeFrame&)L, fp[5]);
+            for (int i = 0; i < npts; i++) pts[i].mbBad = false;
+            nmatches = matcher.SearchByProjection(T, (const Frame&)L, fp[5]);
             result = T.mvpMapPoints;
         } else {
-            FakeKeyFrame KF;
-            KF.keysUn = keypoints(in[14]);
-            KF.mapPoints = vp;
+            KeyFrame KF;
+            KF.mvKeysUn = keypoints(in[14]);
+            KF.mvpMapPoints = vp;
             nmatches = matcher.SearchByProjection(T, &KF, found, fp[5], ip[2]);
             result = T.mvpMapPoints;
         }
         std::vector<int> owner(n ? n : 1, -1);
         for (int i = 0; i < n; i++) {
-            FakeMapPoint* q = result[i];
+            MapPoint* q = result[i];
             if (!q) continue;
             owner[i] = (q >= &pts[0] && q < &pts[0] + npts) ? (int)(q - &pts[0]) : -2;
             if (in[5][i]) owner[i] = -2;  // held on entry (by `pre` or by an already-found point)
@@ -327,36 +208,36 @@ static int matchers_mode(int argc, char** argv) {
         // map point of its own.  Map point ids in the output: candidate i = i, the point held by feature j = npts + j.
         const float* fp = as<float>(in[1]);
         const int* bd = as<int>(in[2]);
-        FakeFrame::mnMinX = bd[0]; FakeFrame::mnMinY = bd[1]; FakeFrame::mnMaxX = bd[2]; FakeFrame::mnMaxY = bd[3];
-        ORB_SLAM::ORBmatcherAccel matcher;
-        FakeKeyFrame KF;
+        Frame::mnMinX = bd[0]; Frame::mnMinY = bd[1]; Frame::mnMaxX = bd[2]; Frame::mnMaxY = bd[3];
+        ORB_SLAM::ORBmatcher matcher;
+        KeyFrame KF;
         KF.fx = fp[0]; KF.fy = fp[1]; KF.cx = fp[2]; KF.cy = fp[3];
-        KF.keysUn = keypoints(in[3]);
-        KF.descriptors = mat_desc(in[4]);
+        KF.mvKeysUn = keypoints(in[3]);
+        KF.mDescriptors = mat_desc(in[4]);
         const int nlev = (int)(in[7].size() / 4);
-        KF.scaleFactors.assign(as<float>(in[7]), as<float>(in[7]) + nlev);
-        const int n = (int)KF.keysUn.size(), npts = (int)in[8].size();
-        std::vector<FakeMapPoint> pts(npts + n);
-        KF.mapPoints.assign(n, (FakeMapPoint*)0);
+        KF.mvScaleFactors.assign(as<float>(in[7]), as<float>(in[7]) + nlev);
+        const int n = (int)KF.mvKeysUn.size(), npts = (int)in[8].size();
+        std::vector<MapPoint> pts(npts + n);
+        KF.mvpMapPoints.assign(n, (MapPoint*)0);
         for (int j = 0; j < n; j++)
             if (in[5][j]) {
-                KF.mapPoints[j] = &pts[npts + j];
+                KF.mvpMapPoints[j] = &pts[npts + j];
                 pts[npts + j].mObservations[&KF] = j;
             }
         cv::Mat pdesc = mat_desc(in[13]);
-        std::vector<FakeMapPoint*> vp(npts);
+        std::vector<MapPoint*> vp(npts);
         for (int i = 0; i < npts; i++) {
-            pts[i].bad = in[8][i] == 2;
-            pts[i].pos = mat_f32(3, 1, as<float>(in[9]) + 3 * i);
-            pts[i].normal = mat_f32(3, 1, as<float>(in[10]) + 3 * i);
-            pts[i].minDist = as<float>(in[11])[i];
-            pts[i].maxDist = as<float>(in[12])[i];
-            pts[i].descriptor = pdesc.row(i);
-            vp[i] = in[8][i] == 1 ? (FakeMapPoint*)0 : &pts[i];
+            pts[i].mbBad = in[8][i] == 2;
+            pts[i].mWorldPos = mat_f32(3, 1, as<float>(in[9]) + 3 * i);
+            pts[i].mNormalVector = mat_f32(3, 1, as<float>(in[10]) + 3 * i);
+            pts[i].mfMinDistance = as<float>(in[11])[i];
+            pts[i].mfMaxDistance = as<float>(in[12])[i];
+            pts[i].mDescriptor = pdesc.row(i);
+            vp[i] = in[8][i] == 1 ? (MapPoint*)0 : &pts[i];
             const int host = as<int>(in[14])[i];
             if (in[8][i] == 3 && host >= 0) {
                 pts[npts + host].mObservations.clear();
-                KF.mapPoints[host] = &pts[i];
+                KF.mvpMapPoints[host] = &pts[i];
                 pts[i].mObservations[&KF] = host;
             }
         }
@@ -364,15 +245,15 @@ static int matchers_mode(int argc, char** argv) {
         int nFused;
         if (mode == "fuse_pose") {
             KF.SetPose(T);
-            nFused = matcher.Fuse<FakeFrame>(&KF, vp, fp[5]);
+            nFused = matcher.Fuse(&KF, vp, fp[5]);
         } else {
-            nFused = matcher.Fuse<FakeFrame>(&KF, T, (const std::vector<FakeMapPoint*>&)vp, fp[5]);
+            nFused = matcher.Fuse(&KF, T, (const std::vector<MapPoint*>&)vp, fp[5]);
         }
         std::vector<int> slot(n ? n : 1, -1), isbad(npts + n ? npts + n : 1, 0), obs(npts + n ? npts + n : 1, -1);
         for (int j = 0; j < n; j++)
-            if (KF.mapPoints[j]) slot[j] = (int)(KF.mapPoints[j] - &pts[0]);
+            if (KF.mvpMapPoints[j]) slot[j] = (int)(KF.mvpMapPoints[j] - &pts[0]);
         for (int i = 0; i < npts + n; i++) {
-            isbad[i] = pts[i].bad;
+            isbad[i] = pts[i].mbBad;
             obs[i] = pts[i].GetIndexInKeyFrame(&KF);
         }
         write_blob(out, &nFused, 4);
@@ -386,34 +267,34 @@ static int matchers_mode(int argc, char** argv) {
         // feature of keyframe 2 its match on entry is observed at, or -1)
         const float* fp = as<float>(in[0]);
         const int* bd = as<int>(in[1]);
-        FakeFrame::mnMinX = bd[0]; FakeFrame::mnMinY = bd[1]; FakeFrame::mnMaxX = bd[2]; FakeFrame::mnMaxY = bd[3];
-        ORB_SLAM::ORBmatcherAccel matcher;
-        FakeKeyFrame KF[2];
-        std::vector<FakeMapPoint> pts[2];
+        Frame::mnMinX = bd[0]; Frame::mnMinY = bd[1]; Frame::mnMaxX = bd[2]; Frame::mnMaxY = bd[3];
+        ORB_SLAM::ORBmatcher matcher;
+        KeyFrame KF[2];
+        std::vector<MapPoint> pts[2];
         const int nlev = (int)(in[2].size() / 4);
         for (int s = 0; s < 2; s++) {
             const int o = 7 + 8 * s;
             KF[s].fx = fp[0]; KF[s].fy = fp[1]; KF[s].cx = fp[2]; KF[s].cy = fp[3];
-            KF[s].keysUn = keypoints(in[o]);
-            KF[s].descriptors = mat_desc(in[o + 1]);
-            KF[s].scaleFactors.assign(as<float>(in[2]), as<float>(in[2]) + nlev);
+            KF[s].mvKeysUn = keypoints(in[o]);
+            KF[s].mDescriptors = mat_desc(in[o + 1]);
+            KF[s].mvScaleFactors.assign(as<float>(in[2]), as<float>(in[2]) + nlev);
             KF[s].SetPose(mat_f32(4, 4, as<float>(in[3 + s])));
-            const int n = (int)KF[s].keysUn.size();
+            const int n = (int)KF[s].mvKeysUn.size();
             pts[s].resize(n);
-            KF[s].mapPoints.assign(n, (FakeMapPoint*)0);
+            KF[s].mvpMapPoints.assign(n, (MapPoint*)0);
             cv::Mat pdesc = mat_desc(in[o + 6]);
             for (int i = 0; i < n; i++) {
-                pts[s][i].bad = in[o + 2][i] == 2;
-                pts[s][i].pos = mat_f32(3, 1, as<float>(in[o + 3]) + 3 * i);
-                pts[s][i].minDist = as<float>(in[o + 4])[i];
-                pts[s][i].maxDist = as<float>(in[o + 5])[i];
-                pts[s][i].descriptor = pdesc.row(i);
-                if (in[o + 2][i] != 1) KF[s].mapPoints[i] = &pts[s][i];
+                pts[s][i].mbBad = in[o + 2][i] == 2;
+                pts[s][i].mWorldPos = mat_f32(3, 1, as<float>(in[o + 3]) + 3 * i);
+                pts[s][i].mfMinDistance = as<float>(in[o + 4])[i];
+                pts[s][i].mfMaxDistance = as<float>(in[o + 5])[i];
+                pts[s][i].mDescriptor = pdesc.row(i);
+                if (in[o + 2][i] != 1) KF[s].mvpMapPoints[i] = &pts[s][i];
             }
         }
         const int n1 = (int)pts[0].size();
-        std::vector<FakeMapPoint> prior(n1 ? n1 : 1);  // the matches vpMatches12 holds on entry
-        std::vector<FakeMapPoint*> vpMatches12(n1, (FakeMapPoint*)0);
+        std::vector<MapPoint> prior(n1 ? n1 : 1);  // the matches vpMatches12 holds on entry
+        std::vector<MapPoint*> vpMatches12(n1, (MapPoint*)0);
         for (int i = 0; i < n1; i++)
             if (in[9][i] == 3) {
                 vpMatches12[i] = &prior[i];
@@ -422,10 +303,10 @@ static int matchers_mode(int argc, char** argv) {
             }
         cv::Mat R12 = mat_f32(3, 3, as<float>(in[5])), t12 = mat_f32(3, 1, as<float>(in[6]));
         const float s12 = fp[4];
-        const int nFound = matcher.SearchBySim3<FakeFrame>(&KF[0], &KF[1], vpMatches12, s12, R12, t12, fp[5]);
+        const int nFound = matcher.SearchBySim3(&KF[0], &KF[1], vpMatches12, s12, R12, t12, fp[5]);
         std::vector<int> idx(n1 ? n1 : 1, -1);
         for (int i = 0; i < n1; i++) {
-            FakeMapPoint* q = vpMatches12[i];
+            MapPoint* q = vpMatches12[i];
             if (!q) continue;
             idx[i] = (!pts[1].empty() && q >= &pts[1][0] && q < &pts[1][0] + pts[1].size()) ? (int)(q - &pts[1][0]) : -3;
         }
@@ -434,21 +315,21 @@ static int matchers_mode(int argc, char** argv) {
     } else if (mode == "triangulate") {
         // blobs: 0 F12 (9 floats), 1 sigma2 per level, 2 int {check_ori}, then per keyframe (3.., 9..): keypoints,
         // descriptors, free (1 = the feature holds no map point), fv nodes, fv start, fv features
-        ORB_SLAM::ORBmatcherAccel matcher(0.6f, as<int>(in[2])[0] != 0);
-        static FakeMapPoint held;
-        FakeKeyFrame KF[2];
+        ORB_SLAM::ORBmatcher matcher(0.6f, as<int>(in[2])[0] != 0);
+        static MapPoint held;
+        KeyFrame KF[2];
         for (int s = 0; s < 2; s++) {
             const int o = 3 + 6 * s;
-            KF[s].keysUn = keypoints(in[o]);
-            KF[s].descriptors = mat_desc(in[o + 1]);
-            const int n = (int)KF[s].keysUn.size();
-            KF[s].mapPoints.assign(n, (FakeMapPoint*)0);
+            KF[s].mvKeysUn = keypoints(in[o]);
+            KF[s].mDescriptors = mat_desc(in[o + 1]);
+            const int n = (int)KF[s].mvKeysUn.size();
+            KF[s].mvpMapPoints.assign(n, (MapPoint*)0);
             for (int i = 0; i < n; i++)
-                if (!in[o + 2][i]) KF[s].mapPoints[i] = &held;
-            KF[s].featVec = feature_vector(in[o + 3], in[o + 4], in[o + 5]);
+                if (!in[o + 2][i]) KF[s].mvpMapPoints[i] = &held;
+            KF[s].mFeatVec = feature_vector(in[o + 3], in[o + 4], in[o + 5]);
             const int nlev = (int)(in[1].size() / 4);
-            KF[s].levelSigma2.assign(as<float>(in[1]), as<float>(in[1]) + nlev);
-            KF[s].scaleFactors.assign(nlev, 1.f);
+            KF[s].mvLevelSigma2.assign(as<float>(in[1]), as<float>(in[1]) + nlev);
+            KF[s].mvScaleFactors.assign(nlev, 1.f);
         }
         std::vector<cv::KeyPoint> k1, k2;
         std::vector<std::pair<size_t, size_t> > pairs;
@@ -465,34 +346,34 @@ static int matchers_mode(int argc, char** argv) {
     } else if (mode == "bow_kf_f" || mode == "bow_kf_kf") {
         // blobs: 0 float {ratio}, 1 int {check_ori}, then per side (2.., 8..): keypoints, descriptors, valid, fv nodes,
         // fv start, fv features
-        ORB_SLAM::ORBmatcherAccel matcher(as<float>(in[0])[0], as<int>(in[1])[0] != 0);
-        FakeKeyFrame KF[2];
-        std::vector<FakeMapPoint> pts[2];
+        ORB_SLAM::ORBmatcher matcher(as<float>(in[0])[0], as<int>(in[1])[0] != 0);
+        KeyFrame KF[2];
+        std::vector<MapPoint> pts[2];
         for (int s = 0; s < 2; s++) {
             const int o = 2 + 6 * s;
-            KF[s].keysUn = keypoints(in[o]);
-            KF[s].descriptors = mat_desc(in[o + 1]);
-            const int n = (int)KF[s].keysUn.size();
+            KF[s].mvKeysUn = keypoints(in[o]);
+            KF[s].mDescriptors = mat_desc(in[o + 1]);
+            const int n = (int)KF[s].mvKeysUn.size();
             pts[s].resize(n);
-            KF[s].mapPoints.assign(n, (FakeMapPoint*)0);
+            KF[s].mvpMapPoints.assign(n, (MapPoint*)0);
             for (int i = 0; i < n; i++) {
                 const unsigned char v = in[o + 2].empty() ? 1 : in[o + 2][i];  // 1 valid, 0 NULL, 2 bad
-                pts[s][i].bad = v == 2;
-                if (v) KF[s].mapPoints[i] = &pts[s][i];
+                pts[s][i].mbBad = v == 2;
+                if (v) KF[s].mvpMapPoints[i] = &pts[s][i];
             }
-            KF[s].featVec = feature_vector(in[o + 3], in[o + 4], in[o + 5]);
+            KF[s].mFeatVec = feature_vector(in[o + 3], in[o + 4], in[o + 5]);
         }
         int nmatches;
-        std::vector<FakeMapPoint*> res;
+        std::vector<MapPoint*> res;
         std::vector<int> idx;
         if (mode == "bow_kf_f") {
-            FakeFrame F;
-            F.mvKeys = F.mvKeysUn = KF[1].keysUn;
-            F.mDescriptors = KF[1].descriptors;
-            F.mvpMapPoints.assign(F.mvKeys.size(), (FakeMapPoint*)0);
-            F.mFeatVec = KF[1].featVec;
+            Frame F;
+            F.mvKeys = F.mvKeysUn = KF[1].mvKeysUn;
+            F.mDescriptors = KF[1].mDescriptors;
+            F.mvpMapPoints.assign(F.mvKeys.size(), (MapPoint*)0);
+            F.mFeatVec = KF[1].mFeatVec;
             // a keyframe whose map-point vector is shorter than its features (the .at() guard of the reference)
-            if (!KF[0].mapPoints.empty()) KF[0].mapPoints.resize(KF[0].mapPoints.size() - KF[0].mapPoints.size() / 16);
+            if (!KF[0].mvpMapPoints.empty()) KF[0].mvpMapPoints.resize(KF[0].mvpMapPoints.size() - KF[0].mvpMapPoints.size() / 16);
             nmatches = matcher.SearchByBoW(&KF[0], F, res);
             idx.assign(res.size() ? res.size() : 1, -1);
             for (size_t i = 0; i < res.size(); i++)
@@ -506,35 +387,35 @@ static int matchers_mode(int argc, char** argv) {
         write_blob(out, &nmatches, 4);
         write_blob(out, idx.data(), sizeof(int) * res.size());
     } else if (mode == "distinct") {
-        ORB_SLAM::ORBmatcherAccel matcher;
+        ORB_SLAM::ORBmatcher matcher;
         cv::Mat d = mat_desc(in[0]);
         std::vector<cv::Mat> v;
         for (int i = 0; i < d.rows; i++) v.push_back(d.row(i));
-        const int best = matcher.DistinctiveDescriptorIndex(v);
+        const int best = ORB_SLAM::DistinctiveDescriptorIndex(v);
         write_blob(out, &best, 4);
     } else if (mode == "undistort") {
         // blobs: 0 keypoints, 1 float {fx, fy, cx, cy, k1, k2, p1, p2}
-        ORB_SLAM::ORBmatcherAccel matcher;
-        FakeFrame F;
+        ORB_SLAM::ORBmatcher matcher;
+        Frame F;
         F.mvKeys = keypoints(in[0]);
         const float* c = as<float>(in[1]);
         const float K[9] = {c[0], 0.f, c[2], 0.f, c[1], c[3], 0.f, 0.f, 1.f};
         F.mK = mat_f32(3, 3, K);
         F.mDistCoef = mat_f32(4, 1, c + 4);
-        matcher.UndistortKeyPoints(F);
+        ORB_SLAM::UndistortKeyPoints(F);
         write_blob(out, F.mvKeysUn.empty() ? 0 : &F.mvKeysUn[0], F.mvKeysUn.size() * sizeof(cv::KeyPoint));
     } else if (mode == "computebow") {
         // blobs: 0 int {L}, 1 parent, 2 node descriptors, 3 weights (double), 4 frame descriptors
-        ORB_SLAM::ORBmatcherAccel matcher;
+        ORB_SLAM::ORBmatcher matcher;
         orbhip_vocabulary* voc = 0;
         const int nn = (int)(in[1].size() / 4);
         if (orbhip_vocabulary_create(&voc, 0, nn, as<int>(in[1]), in[2].data(), as<double>(in[3]), as<int>(in[0])[0]) != ORBHIP_OK) {
             fprintf(stderr, "%s\n", orbhip_last_error());
             return 7;
         }
-        FakeFrame F;
+        Frame F;
         F.mDescriptors = mat_desc(in[4]);
-        matcher.ComputeBoW(F, voc, DBoW2::L1);
+        ORB_SLAM::ComputeBoW(F, voc);
         orbhip_vocabulary_destroy(voc);
         std::vector<int> words, nodes, start(1, 0), feat;
         std::vector<double> vals;
@@ -588,7 +469,7 @@ int main(int argc, char** argv) {
     if (extractor.GetLevels() != 8 || extractor.GetScaleFactor() != 1.2f) return 5;
     int n = (int)keys.size();
     if (n != descriptors.rows) return 6;
-    int dist01 = n >= 2 ? ORB_SLAM::ORBmatcherAccel::DescriptorDistance(descriptors.row(0), descriptors.row(1)) : -1;
+    int dist01 = n >= 2 ? ORB_SLAM::ORBmatcher::DescriptorDistance(descriptors.row(0), descriptors.row(1)) : -1;
     f = fopen(argv[5], "wb");
     fwrite(&n, 4, 1, f);
     fwrite(&dist01, 4, 1, f);
@@ -599,22 +480,22 @@ int main(int argc, char** argv) {
     for (int y = 0; y < rows; y++)
         for (int x = 0; x < cols; x++) buf2[(size_t)y * cols + x] = buf[(size_t)((y + rows - 3) % rows) * cols + (x + cols - 5) % cols];
     cv::Mat im2(rows, cols, CV_8U, buf2.data(), (size_t)cols);
-    FakeFrame F1, F2;
-    FakeFrame::mnMinX = 0; FakeFrame::mnMinY = 0; FakeFrame::mnMaxX = cols; FakeFrame::mnMaxY = rows;
+    Frame F1, F2;
+    Frame::mnMinX = 0; Frame::mnMinY = 0; Frame::mnMaxX = cols; Frame::mnMaxY = rows;
     F1.mvKeysUn = keys;
     F1.mDescriptors = descriptors;
     extractor(im2, cv::Mat(), F2.mvKeysUn, F2.mDescriptors);
-    static FakeMapPoint good, bad;
-    bad.bad = true;
+    static MapPoint good, bad;
+    bad.mbBad = true;
     F1.mvpMapPoints.resize(F1.mvKeysUn.size());
-    for (size_t i = 0; i < F1.mvpMapPoints.size(); i++) F1.mvpMapPoints[i] = i % 7 == 0 ? (FakeMapPoint*)0 : (i % 11 == 0 ? &bad : &good);
-    F2.mvpMapPoints.assign(F2.mvKeysUn.size(), (FakeMapPoint*)0);
-    ORB_SLAM::ORBmatcherAccel matcher(0.9f, true);
+    for (size_t i = 0; i < F1.mvpMapPoints.size(); i++) F1.mvpMapPoints[i] = i % 7 == 0 ? (MapPoint*)0 : (i % 11 == 0 ? &bad : &good);
+    F2.mvpMapPoints.assign(F2.mvKeysUn.size(), (MapPoint*)0);
+    ORB_SLAM::ORBmatcher matcher(0.9f, true);
     std::vector<cv::Point2f> prev(F1.mvKeysUn.size());
     for (size_t i = 0; i < prev.size(); i++) prev[i] = F1.mvKeysUn[i].pt;
     std::vector<int> m12;
     int nInit = matcher.SearchForInitialization(F1, F2, prev, m12, 100);
-    std::vector<FakeMapPoint*> mp2;
+    std::vector<MapPoint*> mp2;
     int nWin = matcher.WindowSearch(F1, F2, 50, mp2, 0);
     int n2 = (int)F2.mvKeysUn.size();
     fwrite(&n2, 4, 1, f);
@@ -630,23 +511,23 @@ int main(int argc, char** argv) {
     }
     // SearchByProjection(Frame&, vector<MapPoint*>&, th): one map point per keypoint of frame 1, predicted at
     // that keypoint moved by the known image shift, matched into frame 2
-    std::vector<FakeMapPoint> pts(n);
-    std::vector<FakeMapPoint*> vp(n);
+    std::vector<MapPoint> pts(n);
+    std::vector<MapPoint*> vp(n);
     for (int i = 0; i < n; i++) {
-        pts[i].bad = i % 13 == 0;
+        pts[i].mbBad = i % 13 == 0;
         pts[i].mbTrackInView = i % 5 != 0;
         pts[i].mnTrackScaleLevel = keys[i].octave;
         pts[i].mTrackViewCos = i % 3 == 0 ? 0.9985f : 0.99f;
         pts[i].mTrackProjX = keys[i].pt.x + 5.f;
         pts[i].mTrackProjY = keys[i].pt.y + 3.f;
-        pts[i].descriptor = descriptors.row(i);
+        pts[i].mDescriptor = descriptors.row(i);
         vp[i] = &pts[i];
     }
     F2.mvScaleFactors.resize(8);
     F2.mvScaleFactors[0] = 1.f;
     for (int l = 1; l < 8; l++) F2.mvScaleFactors[l] = F2.mvScaleFactors[l - 1] * 1.2f;
-    for (int i = 0; i < n2; i++) F2.mvpMapPoints[i] = i % 9 == 0 ? &good : (FakeMapPoint*)0;
-    ORB_SLAM::ORBmatcherAccel matcher8(0.8f, true);
+    for (int i = 0; i < n2; i++) F2.mvpMapPoints[i] = i % 9 == 0 ? &good : (MapPoint*)0;
+    ORB_SLAM::ORBmatcher matcher8(0.8f, true);
     int nProj = matcher8.SearchByProjection(F2, vp, 3.f);
     fwrite(&nProj, 4, 1, f);
     for (int i = 0; i < n2; i++) {

@@ -147,6 +147,68 @@ def test_fuse_probes(orb, orbref, form):
     assert check(orb, probes, refs) > 1500
 
 
+@pytest.mark.parametrize("window", [15, 50])
+def test_window_probes(orb, orbref, window):
+    """SearchByProjection(F1, F2, windowSize, ...) (src/ORBmatcher.cc:545-566): radius = the window, the source
+    keypoint's octave the only level, no depth or image test."""
+    rng = np.random.default_rng(241)
+    scenes, poses, refs, kps, skips = [], [], [], [], []
+    for n in SIZES:
+        T2 = pose(rng)
+        s2 = Scene(orbref, rng, n, 640, 480, T2)
+        kp1 = np.zeros(n, orbref.KP_DTYPE)
+        kp1["octave"] = s2.level
+        skip1 = (rng.random(n) < 0.2).astype(np.uint8)
+        refs.append(orbref.sbp_frames(kp1, s2.mp_desc, skip1, s2.pos, T2, s2.K, s2.kp, s2.desc, s2.bounds, s2.taken, window, 0.8)[2])
+        scenes.append(s2), poses.append(T2), kps.append(kp1), skips.append(skip1)
+    _, probes = device_probes(orb, orb.ORBmatcher.PROBES_WINDOW, scenes, poses, float(window), src_kp=kps, skip=skips)
+    assert check(orb, probes, refs) > 2000
+
+
+@pytest.mark.parametrize("n,th", [(1800, 7.5), (0, 7.5), (1, 7.5), (60, 10.0)])
+def test_sim3_probes(orb, orbref, n, th):
+    """Both directions of SearchBySim3 (src/ORBmatcher.cc:1330-1375, :1415-1460): pose of the point's own keyframe, then
+    the similarity, each product rounded to float; distance range on the distance in the target camera."""
+    import torch
+    from test_gpu_fuse import two_views
+    rng = np.random.default_rng(191 + n)
+    w, h, s12 = 752, 480, np.float32(1.07)
+    T1, T2 = pose(rng), pose(rng)
+    K, (v1, v2), T2s, R12, t12, mp_desc, level = two_views(orbref, rng, n, w, h, T1, T2, float(s12))
+    bounds = [0, 0, w, h]
+    side = []
+    for v, other in ((v1, v2), (v2, v1)):
+        k = len(v["kp"])
+        has = v["owner"] >= 0
+        o = np.where(has, v["owner"], 0)
+        skip = (~has | (rng.random(k) < 0.1)).astype(np.uint8)
+        pos = np.where(has[:, None], v["pos"][o] if n else np.zeros((k, 3), np.float32), 0).astype(np.float32)
+        d_other = other["dist"][o] if n else np.zeros(k)
+        min_d = (d_other / SCALE[level[o] if n else np.zeros(k, int)] * rng.uniform(0.85, 1.18, k)).astype(np.float32)
+        max_d = (min_d * rng.choice(np.array([1.1, 1.2 ** 7.5], np.float32), k, p=[0.1, 0.9])).astype(np.float32)
+        d = np.where(has[:, None], mp_desc[o] if n else np.zeros((k, 32), np.uint8), 0).astype(np.uint8)
+        side.append((skip, pos, min_d, max_d, d))
+    ref = orbref.search_by_sim3(v1["kp"], v1["desc"], v2["kp"], v2["desc"], bounds, K, SCALE, T1, T2s, s12, R12, t12, th,
+                                *side[0], *side[1])
+    m = orb.ORBmatcher(0.75, True)
+    to2, to1 = m.sim3_projections(s12, R12, t12, K)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    valid = 0
+    for (skip, pos, min_d, max_d, _), T, to, want in ((side[0], T1, to2, ref[4]), (side[1], T2s, to1, ref[5])):
+        k = len(skip)
+        pcap = max(k, 1)
+        pad = lambda a, shape: np.concatenate([a, np.zeros((pcap - k,) + shape, a.dtype)]) if k < pcap else a  # noqa: E731
+        probes = m.BuildProbesSim3(m.projections([T], K), to, bounds, SCALE, cu(pad(pos, (3,))[None]), cu(np.array([k], np.int32)), th,
+                                   cu(pad(min_d, ())[None]), cu(pad(max_d, ())[None]), skip=cu(pad(skip, ())[None]))
+        m.synchronize()
+        got = probes.cpu().numpy()[0, :k]
+        exp = np.ascontiguousarray(want).view(np.uint8).reshape(-1, 32)
+        assert np.array_equal(got, exp), "%d probes differ" % int((got != exp).any(axis=1).sum())
+        valid += int(want["valid"].sum())
+    if n >= 1000:
+        assert valid > 1000
+
+
 def test_build_probes_argument_errors(orb):
     import torch
     m = orb.ORBmatcher(0.8, True)

@@ -32,7 +32,7 @@ def test_cpp_shim_matches_oracle(orb, orbref, synth, tmp_path):
     assert np.array_equal(desc, rdesc)
     assert dist01 == orbref.hamming(rdesc[0], rdesc[1])
 
-    # second frame + the forwarding SearchForInitialization / WindowSearch bodies (shim/ORBmatcher_accel.h)
+    # second frame + the forwarding SearchForInitialization / WindowSearch bodies (shim/ORBmatcher.cc)
     n2 = int(np.frombuffer(blob[o:o + 4], np.int32)[0])
     o += 4
     kp2 = np.frombuffer(blob[o:o + 28 * n2], orb.KP_DTYPE)

@@ -1,4 +1,4 @@
-"""The forwarding C++ bodies of orb-slam2_amd/shim/ORBmatcher_accel.h for the matcher methods that work on
+"""The forwarding C++ bodies of orb-slam2_amd/shim/ORBmatcher.cc for the matcher methods that work on
 poses, map points and BoW vectors: four ORBmatcher::SearchByProjection overloads (src/ORBmatcher.cc:297-418,
 :530-605, :1518-1631, :1633-1757), both ORBmatcher::SearchByBoW (:158-295, :726-861),
 MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:191-256), Frame::UndistortKeyPoints and

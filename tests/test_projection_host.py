@@ -57,3 +57,37 @@ def test_projection_from_pose_and_sim3():
         R, t, Ow = expected(D)
         assert np.array_equal(np.array(out.Rcw[:], np.float32).reshape(3, 3), R)
         assert np.array_equal(np.array(out.tcw[:], np.float32), t) and np.array_equal(np.array(out.Ow[:], np.float32), Ow)
+
+
+def test_probes_from_tracked_fields():
+    """orbhip_probes_from_tracked against the oracle's restatement of src/ORBmatcher.cc:52-81 (probe records byte for
+    byte; the oracle builds them inside its local-map matcher) and by hand: 2.5 or 4.0 by viewing cosine, times th unless
+    th == 1, times the scale factor of the predicted level; levels level-1 .. level."""
+    import os
+    import sys
+    orb = importlib.import_module("orb-slam2_amd")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+    import orbref
+    sf = np.ones(8, np.float32)
+    for l in range(1, 8):
+        sf[l] = sf[l - 1] * np.float32(1.2)
+    rng = np.random.default_rng(77)
+    n = 500
+    level = rng.integers(0, 8, n).astype(np.int32)
+    view_cos = rng.choice(np.array([0.9979, 0.998, 0.99801, 0.5, 1.0], np.float32), n)
+    px, py = rng.uniform(0, 640, n).astype(np.float32), rng.uniform(0, 480, n).astype(np.float32)
+    in_view = (rng.random(n) < 0.8).astype(np.uint8)
+    bad = (rng.random(n) < 0.1).astype(np.uint8)
+    kp = np.zeros(4, orbref.KP_DTYPE)
+    desc = np.zeros((4, 32), np.uint8)
+    for th in (1.0, 3.0, 5.0):
+        want = orbref.sbp_local_map(kp, desc, [0, 0, 640, 480], sf, np.zeros(4, np.uint8), in_view, bad, level, view_cos, px, py,
+                                    np.zeros((n, 32), np.uint8), th, 0.8)[2]
+        got = orb.ORBmatcher.probes_from_tracked(np.stack([px, py], 1), view_cos, level, (1 - in_view) | bad, th, sf)
+        assert np.array_equal(got.view(np.uint8), np.ascontiguousarray(want).view(np.uint8))
+    one = orb.ORBmatcher.probes_from_tracked([[10.0, 20.0]], [0.999], [3], [0], 3.0, sf)[0]
+    assert one["r"] == np.float32(np.float32(2.5 * 3.0) * sf[3]) and (one["min_level"], one["max_level"], one["valid"]) == (2, 3, 1)
+    one = orb.ORBmatcher.probes_from_tracked([[10.0, 20.0]], [0.997], [0], [0], 1.0, sf)[0]
+    assert one["r"] == np.float32(4.0) and (one["min_level"], one["max_level"]) == (-1, 0)
+    # the comparison is float against the double literal 0.998, as in the reference: the float nearest to 0.998 lies above it
+    assert orb.ORBmatcher.probes_from_tracked([[10.0, 20.0]], [0.998], [0], [0], 1.0, sf)[0]["r"] == np.float32(2.5)
