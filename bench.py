@@ -513,13 +513,59 @@ def knn_roofline(rate, r_bcnt, kernel="k_knn2_mm"):
                             "unit": "v_bcnt lane-ops/s", "frac": round(rate * 8 / r_bcnt, 4) if r_bcnt else None}}
 
 
-def knn_pairs_leg(orb, torch, dev, m, pairs=4096, nq=2000, nt=2000, reps=5):
-    """4096 independent pairs of 2000 x 2000 descriptors: returns (median ms, device tensors)."""
-    cuda = "cuda:%d" % dev
+def device_descriptors(torch, cuda, pairs, nq, nt, seed):
+    """Query and train sets generated on the device with the make-up the configuration specifies (and
+    synth.synth_descriptors has on the host): uniform random bytes; a twentieth of each train set overwritten with
+    copies of other rows of the set; a quarter of the queries copies of a random train row of their pair with 0 - 40
+    randomly chosen bits flipped (a bit drawn twice flips back, as in the host generator)."""
     g = torch.Generator(device=cuda)
-    g.manual_seed(1)
+    g.manual_seed(seed)
     q = torch.randint(0, 256, (pairs, nq, 32), dtype=torch.uint8, device=cuda, generator=g)
     t = torch.randint(0, 256, (pairs, nt, 32), dtype=torch.uint8, device=cuda, generator=g)
+    pidx = torch.arange(pairs, device=cuda)[:, None]
+    ndup = max(1, nt // 20)
+    dst = torch.randint(0, nt, (pairs, ndup), device=cuda, generator=g)
+    src = torch.randint(0, nt, (pairs, ndup), device=cuda, generator=g)
+    t[pidx, dst] = t[pidx, src]
+    ncopy = nq // 4
+    qi = torch.rand((pairs, nq), device=cuda, generator=g).argsort(dim=1)[:, :ncopy]  # ncopy distinct queries per pair
+    ti = torch.randint(0, nt, (pairs, ncopy), device=cuda, generator=g)
+    planted = t[pidx, ti].clone()
+    nflip = torch.randint(0, 41, (pairs, ncopy), device=cuda, generator=g)
+    bits = torch.randint(0, 256, (pairs, ncopy, 40), device=cuda, generator=g)
+    for k in range(40):
+        on = (nflip > k).to(torch.uint8)
+        byte = (bits[:, :, k] >> 3)[:, :, None]
+        mask = (on * (1 << (bits[:, :, k] & 7)).to(torch.uint8))[:, :, None]
+        planted.scatter_(2, byte, planted.gather(2, byte) ^ mask)
+    q[pidx, qi] = planted
+    return q, t
+
+
+def falling_distance_descriptors(torch, cuda, pairs, nq, nt, seed, distinct=64):
+    """A bad case for a streaming two-smallest scan: inside a pair every query is a near-copy of one base descriptor
+    and train row j differs from that base in about 200 - 180 j / nt bits, so distances keep falling along the scan and
+    the running second-best is beaten again and again to the very end.  `distinct` pairs are generated and repeated."""
+    g = torch.Generator(device=cuda)
+    g.manual_seed(seed)
+    base = torch.randint(0, 256, (distinct, 1, 32), dtype=torch.uint8, device=cuda, generator=g)
+    weights = (1 << torch.arange(8, device=cuda)).to(torch.uint8)
+
+    def flips(rows, prob):  # [distinct, rows, 32] bytes whose bits are set with probability prob[row]
+        r = torch.rand((distinct, rows, 32, 8), device=cuda, generator=g) < prob[None, :, None, None]
+        return (r.to(torch.uint8) * weights).sum(dim=3).to(torch.uint8)
+
+    p_t = (200.0 - 180.0 * torch.arange(nt, device=cuda) / nt) / 256.0
+    t = base ^ flips(nt, p_t)
+    q = base ^ flips(nq, torch.full((nq,), 4.0 / 256.0, device=cuda))
+    rep = (pairs + distinct - 1) // distinct
+    return q.repeat(rep, 1, 1)[:pairs].contiguous(), t.repeat(rep, 1, 1)[:pairs].contiguous()
+
+
+def knn_pairs_leg(orb, torch, dev, m, pairs=4096, nq=2000, nt=2000, reps=5, data=None):
+    """4096 independent pairs of 2000 x 2000 descriptors: returns (median ms, device tensors)."""
+    cuda = "cuda:%d" % dev
+    q, t = data if data is not None else device_descriptors(torch, cuda, pairs, nq, nt, seed=1)
     o = torch.zeros((3, pairs, nq), dtype=torch.int32, device=cuda)
     torch.cuda.synchronize(dev)
 
@@ -654,10 +700,11 @@ def single_gpu_legs(orb, torch, dev, wl0):
         k = 10 if w < 1500 else 5
         dt = wl.timed(k, 2)
         roof, nkp = extract_roofline(wl, 3)
-        rr = [orbref.RefExtractor(nf, 1.2, 8, 1, 20)(fr[i]) for i in range(2)]
+        nchk = 16  # of the 256 frames of the chunk (1080p: 16 of its 32 distinct ones), oracle on all host threads
+        rr = cpu_extract(fr, nf, threads, nchk)[1]
         res[name] = {"frames_per_sec": round(bb * k / dt, 1), "batch": bb, "ms_per_step": round(dt / k * 1e3, 3),
                      "keypoints_per_frame": round(nkp, 1), "roofline": roof,
-                     "parity_frames_checked": 2, "parity_frames_mismatching": wl.mismatching(rr)}
+                     "parity_frames_checked": nchk, "parity_frames_mismatching": wl.mismatching(rr)}
         del wl, fr
 
     # ---- Hamming kNN k=2: 4096 pairs of 2000 x 2000 descriptors (1.6384e10 comparisons) ------------
@@ -674,6 +721,8 @@ def single_gpu_legs(orb, torch, dev, wl0):
     ok = all(np.array_equal(oo[0, i], rN[i][0]) and np.array_equal(oo[1, i], rN[i][1]) and np.array_equal(oo[2, i], rN[i][2])
              for i in range(len(rN)))
     res["hamming_knn2"] = {"pairs": pairs, "nq": nq, "nt": nt, "comparisons_per_sec": float("%.4g" % rate),
+                           "data": "per pair: uniform random descriptors, 5 % of the train rows copies of other rows, 25 % of "
+                                   "the queries near-copies of a train row (0 - 40 bits flipped), generated on the device",
                            "ms": round(best, 4), "roofline": knn_roofline(rate, r_bcnt),
                            "sustained_lane_ops_per_sec": {"v_bcnt_u32_b32": float("%.4g" % r_bcnt),
                                                           "xor_bcnt_mix": float("%.4g" % r_mix),
@@ -693,12 +742,31 @@ def single_gpu_legs(orb, torch, dev, wl0):
         "bound": "valu", "kernel": "k_knn2", "achieved": float("%.4g" % (rate_pc * 8)), "peak": float("%.4g" % r_bcnt),
         "unit": "v_bcnt lane-ops/s", "frac": round(rate_pc * 8 / r_bcnt, 4) if r_bcnt else None, "ceiling_of_the_formulation": 0.64}
     del q, t, o
+    # the same shape on two other inputs: featureless noise (nothing planted: the usual case of an unrelated frame
+    # pair) and distances that fall along the whole scan (the bad case of a streaming two-smallest scan)
+    g0 = torch.Generator(device=cuda)
+    g0.manual_seed(1)
+    noise = (torch.randint(0, 256, (pairs, nq, 32), dtype=torch.uint8, device=cuda, generator=g0),
+             torch.randint(0, 256, (pairs, nt, 32), dtype=torch.uint8, device=cuda, generator=g0))
+    for name, data in (("uniform_noise", noise), ("falling_distances", falling_distance_descriptors(torch, cuda, pairs, nq, nt, 3))):
+        ms_x, _, qx, tx, ox = knn_pairs_leg(orb, torch, dev, m, pairs, nq, nt, reps=4, data=data)
+        rate_x = pairs * nq * nt / (ms_x * 1e-3)
+        rx = orbref.knn2(qx[0].cpu().numpy(), tx[0].cpu().numpy())
+        ohx = ox[:, 0].cpu().numpy()
+        m.set_scan_kernel("popcount")
+        ms_xp = knn_pairs_leg(orb, torch, dev, m, pairs, nq, nt, reps=2, data=data)[0]
+        m.set_scan_kernel("matrix")
+        res["hamming_knn2"][name] = {
+            "comparisons_per_sec": float("%.4g" % rate_x), "ms": round(ms_x, 4), "frac": knn_roofline(rate_x, r_bcnt)["frac"],
+            "popcount_kernel_comparisons_per_sec": float("%.4g" % (pairs * nq * nt / (ms_xp * 1e-3))),
+            "popcount_kernel_frac": round(pairs * nq * nt / (ms_xp * 1e-3) * 8 / r_bcnt, 4) if r_bcnt else None,
+            "parity_pair0": bool(np.array_equal(ohx[0], rx[0]) and np.array_equal(ohx[1], rx[1]) and np.array_equal(ohx[2], rx[2]))}
+        del qx, tx, ox, data
+    del noise
     # ---- frame-vs-map shard: 4000 queries against the 1.25 M map rows one GPU of eight owns ---------
     nq2, nt2 = 4000, 1250000
-    g = torch.Generator(device=cuda)
-    g.manual_seed(2)
-    q2 = torch.randint(0, 256, (nq2, 32), dtype=torch.uint8, device=cuda, generator=g)
-    t2 = torch.randint(0, 256, (nt2, 32), dtype=torch.uint8, device=cuda, generator=g)
+    q2, t2 = device_descriptors(torch, cuda, 1, nq2, nt2, seed=2)
+    q2, t2 = q2[0], t2[0]
     o2 = torch.zeros((3, nq2), dtype=torch.int32, device=cuda)
     torch.cuda.synchronize(dev)
     # the first calls after an idle or differently loaded period run slower (the clock follows the load): 16 calls,
@@ -782,7 +850,8 @@ def dist_legs(orb, torch, dist, dev, rank, world, barrier, max_over_ranks, gloo=
     steps = 3
     dt = timed(wl.step, wl.sync, steps)
     if rank == 0:
-        rr = [oracle().RefExtractor(nf, 1.2, 8, 1, 20)(pool[(f0 + i) % distinct]) for i in range(2)]
+        nchk = min(8, f1 - f0)
+        rr = cpu_extract(np.stack([pool[(f0 + i) % distinct] for i in range(nchk)]), nf, min(8, os.cpu_count() or 1), nchk)[1]
         P = pyramid_pixels(wl.ext, wl.ext.GetLevels())
         nkp = float(wl.d_n.float().mean().item())
         fps = total * steps / dt
@@ -791,7 +860,7 @@ def dist_legs(orb, torch, dist, dev, rank, world, barrier, max_over_ranks, gloo=
             "frames_per_sec": round(fps, 1), "ms_per_step": round(dt / steps * 1e3, 3), "keypoints_per_frame": round(nkp, 1),
             "algorithmic_gb_per_sec": round(fps * (5 * P + 60 * nkp) / 1e9, 1),
             "frac_of_hbm_peak_all_ranks": round(fps * (5 * P + 60 * nkp) / 1e9 / (HBM_PEAK_GBS * world), 5),
-            "collective": None, "parity_frames_checked": 2, "parity_frames_mismatching": wl.mismatching(rr)}
+            "collective": None, "parity_frames_checked": nchk, "parity_frames_mismatching": wl.mismatching(rr)}
     del wl, pool
 
     # ---- 4000 queries against a 10 M-row map, one index-contiguous shard per rank --------------------
@@ -865,10 +934,10 @@ def dist_legs(orb, torch, dist, dev, rank, world, barrier, max_over_ranks, gloo=
 
 
 def bow_leg(orb, torch, dev, orbref, m):
-    """Vocabulary descent of 256 x 2000 descriptors through a synthetic k = 10, L = 5 tree (111 k nodes),
-    next to the oracle on one thread for 2000 descriptors."""
-    k, L, n = 10, 5, 256 * 2000
-    parent, desc, weight = orb.synth.synth_vocabulary(k, L, seed=1, tie_share=0.05)
+    """Vocabulary descent of 256 x 2000 descriptors through a synthetic tree of the ORB vocabulary's shape (k = 10,
+    L = 6: 1,111,111 nodes, 35 MB of node descriptors), next to the oracle on one thread for 2000 descriptors."""
+    k, L, n = 10, 6, 256 * 2000
+    parent, desc, weight = orb.synth.synth_vocabulary_large(k, L, seed=1, tie_share=0.05)
     voc = orb.ORBVocabulary(parent, desc, weight, L, device=dev)
     cuda = "cuda:%d" % dev
     rng = np.random.default_rng(2)
@@ -906,8 +975,8 @@ def bow_leg(orb, torch, dev, orbref, m):
     F1 = orb.FrameBatch(mm, torch.from_numpy(kp).to(cuda), torch.from_numpy(d1).to(cuda), cnt, [0, 0, 1280, 720])
     F2 = orb.FrameBatch(mm, torch.from_numpy(kp).to(cuda), torch.from_numpy(d2).to(cuda), cnt, [0, 0, 1280, 720])
     t0 = time.perf_counter()
-    F1.ComputeBoW(voc, 3, node_cap=1024)
-    F2.ComputeBoW(voc, 3, node_cap=1024)
+    F1.ComputeBoW(voc, 4, node_cap=1024)
+    F2.ComputeBoW(voc, 4, node_cap=1024)
     t_bow = (time.perf_counter() - t0) / 2
     ones = torch.ones((b, nf), dtype=torch.uint8, device=cuda)
     tsb = []

@@ -101,3 +101,53 @@ def synth_vocabulary(k, L, seed=0, tie_share=0.15, stop_share=0.05):
     weight[leaf] = rng.uniform(0.5, 9.0, int(leaf.sum()))
     weight[leaf & (rng.random(n) < stop_share)] = 0.0
     return parent, desc, weight
+
+
+def synth_vocabulary_large(k, L, seed=0, tie_share=0.05, stop_share=0.05):
+    """synth_vocabulary for trees of the size of the ORB vocabulary (k = 10, L = 6: 1,111,111 nodes), generated level
+    by level with array operations; same numbering (a node's children are consecutive and are created when a
+    depth-first walk reaches the node), same make-up (children resemble their parent, a share of siblings repeat
+    the descriptor of the sibling before them, a share of words are stopped), its own random stream.
+    Returns (parent int32[n], desc uint8[n, 32], weight float64[n])."""
+    rng = np.random.default_rng(seed)
+    # size of a complete subtree whose root sits at depth d
+    sub = [0] * (L + 2)
+    for d in range(L, -1, -1):
+        sub[d] = 1 + (k * sub[d + 1] if d < L else 0)
+    n = sub[0]
+    # Children of a node are numbered when the depth-first walk visits the node: the walk visits the internal nodes in
+    # preorder, and the j-th internal node visited owns ids 1 + j k .. k + j k.  Preorder rank among internal nodes of
+    # the c-th child (depth d + 1) of a node with rank r: r + 1 + c * (internal nodes of a subtree rooted at depth d + 1).
+    internal = [0] * (L + 2)
+    for d in range(L - 1, -1, -1):
+        internal[d] = 1 + k * internal[d + 1]
+    parent = np.zeros(n, np.int32)
+    depth = np.zeros(n, np.int8)
+    ids = np.array([0], np.int64)    # node ids of the current level, in walk order
+    rank = np.array([0], np.int64)   # their preorder ranks among internal nodes
+    levels = [ids]
+    for d in range(L):
+        child_ids = (1 + rank[:, None] * k + np.arange(k)[None, :]).reshape(-1)
+        parent[child_ids] = np.repeat(ids, k)
+        depth[child_ids] = d + 1
+        child_rank = (rank[:, None] + 1 + np.arange(k)[None, :] * internal[d + 1]).reshape(-1)
+        ids, rank = child_ids, child_rank
+        levels.append(ids)
+    desc = np.zeros((n, 32), np.uint8)
+    desc[0] = rng.integers(0, 256, 32, dtype=np.uint8)
+    for d in range(1, L + 1):
+        idl = levels[d]
+        own = rng.integers(0, 256, (len(idl), 32), dtype=np.uint8)
+        keep = rng.integers(0, 256, (len(idl), 32), dtype=np.uint8) & rng.integers(0, 256, (len(idl), 32), dtype=np.uint8)
+        new = (desc[parent[idl]] & ~keep) | (own & keep)
+        # a tied node repeats the sibling before it (chains allowed): take the descriptor of the last untied node of its run
+        tie = rng.random(len(idl)) < tie_share
+        tie[::k] = False  # a first child has no sibling before it
+        src = np.maximum.accumulate(np.where(tie, 0, np.arange(len(idl))))
+        desc[idl] = new[src]
+    weight = np.zeros(n, np.float64)
+    leaves = levels[L]
+    w = rng.uniform(0.5, 9.0, len(leaves))
+    w[rng.random(len(leaves)) < stop_share] = 0.0
+    weight[leaves] = w
+    return parent, desc, weight

@@ -48,21 +48,31 @@ class ORBVocabulary:
             k, L, scoring, weighting = (int(v) for v in head[:4])
             if k < 0 or k > 20 or L < 1 or L > 10 or scoring < 0 or scoring > 5 or weighting < 0 or weighting > 3:
                 return None
-            rows = [ln.split() for ln in f if ln.strip()]
-        n = len(rows) + 1
+            body = f.read()
+        nrows = sum(1 for ln in body.splitlines() if ln.strip()) if len(body) < (1 << 16) else body.count("\n") + (not body.endswith("\n"))
+        # every number of the node lines in one pass (the real vocabulary has 1.1 M lines of 35 fields); integers up to
+        # 2^53 and the weights' decimal strings convert to the same doubles as a per-field conversion would give
+        vals = np.fromstring(body, dtype=np.float64, sep=" ") if body.strip() else np.zeros(0)
+        if nrows and vals.size == nrows * 35:
+            tab = vals.reshape(nrows, 35)
+        else:  # not the regular shape: find the line that is wrong
+            rows = [ln.split() for ln in body.splitlines() if ln.strip()]
+            for i, t in enumerate(rows, start=1):
+                if len(t) != 35:
+                    raise ValueError("%s: node line %d has %d fields, expected 35" % (filename, i, len(t)))
+            tab = np.array([[float(v) for v in t] for t in rows], np.float64).reshape(len(rows), 35)
+        n = len(tab) + 1
         parent = np.zeros(n, np.int32)
         desc = np.zeros((n, 32), np.uint8)
         weight = np.zeros(n, np.float64)
         leaf = np.zeros(n, bool)
-        for i, t in enumerate(rows, start=1):
-            if len(t) != 35:
-                raise ValueError("%s: node line %d has %d fields, expected 35" % (filename, i, len(t)))
-            parent[i] = int(t[0])
-            if not 0 <= parent[i] < i:
-                raise ValueError("%s: node %d names parent %d" % (filename, i, parent[i]))
-            leaf[i] = int(t[1]) > 0
-            desc[i] = [int(v) for v in t[2:34]]
-            weight[i] = float(t[34])
+        parent[1:] = tab[:, 0].astype(np.int32)
+        wrong = np.nonzero((parent[1:] < 0) | (parent[1:] >= np.arange(1, n)))[0]
+        if len(wrong):
+            raise ValueError("%s: node %d names parent %d" % (filename, wrong[0] + 1, parent[wrong[0] + 1]))
+        leaf[1:] = tab[:, 1] > 0
+        desc[1:] = tab[:, 2:34].astype(np.uint8)
+        weight[1:] = tab[:, 34]
         has_child = np.zeros(n, bool)
         has_child[parent[1:]] = True
         if (leaf[1:] == has_child[1:]).any():
@@ -77,11 +87,14 @@ class ORBVocabulary:
         has_child = np.zeros(n, bool)
         has_child[self.parent[1:]] = True
         kk = k if k is not None else getattr(self, "k", int(np.bincount(self.parent[1:]).max()) if n > 1 else 0)
+        lut = np.array([str(i) for i in range(256)], dtype=object)
         with open(filename, "w") as f:
             f.write("%d %d  %d %d\n" % (kk, self.L, self.scoring, self.weighting))
-            for i in range(1, n):
-                f.write("%d %d %s %s\n" % (self.parent[i], 0 if has_child[i] else 1, " ".join(str(int(b)) for b in self.desc[i]),
-                                           repr(float(self.weight[i]))))
+            for a in range(1, n, 65536):  # in blocks: the byte -> text conversion is a table lookup per block
+                b = min(n, a + 65536)
+                txt = lut[self.desc[a:b]]
+                par, lf, wt = self.parent[a:b].tolist(), (~has_child[a:b]).astype(int).tolist(), self.weight[a:b].tolist()
+                f.write("".join("%d %d %s %r\n" % (par[i], lf[i], " ".join(txt[i]), wt[i]) for i in range(b - a)))
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

@@ -169,3 +169,36 @@ def test_vocabulary_text_file_round_trip(orb, orbref, synth, tmp_path):
     bad = tmp_path / "bad.txt"
     bad.write_text("25 3 0 0\n")
     assert orb.ORBVocabulary.loadFromTextFile(str(bad)) is None
+
+
+def test_vocabulary_of_the_real_shape_k10_L6(orb, orbref, synth, tmp_path):
+    """The shape of the vocabulary the reference loads (ORBvoc: k = 10, L = 6, 1,111,111 nodes, 1 M words,
+    Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1337-1420) on a synthetic tree of that size: the transform with the
+    levelsup Frame::ComputeBoW uses (4) against the oracle, then the tree through the ORBvoc text format (155 MB) and
+    back, same arrays and same transform."""
+    k, L = 10, 6
+    parent, desc, weight = synth.synth_vocabulary_large(k, L, seed=61)
+    assert len(parent) == 1111111
+    voc = orb.ORBVocabulary(parent, desc, weight, L)
+    assert voc.size() == 10 ** 6
+    ref = orbref.RefVocabulary(parent, desc, weight, L)
+    m = orb.ORBmatcher()
+    rng = np.random.default_rng(67)
+    n = 20000
+    f = desc[rng.integers(1, len(desc), n)] ^ (rng.integers(0, 256, (n, 32), dtype=np.uint8)
+                                                & rng.integers(0, 256, (n, 32), dtype=np.uint8)
+                                                & rng.integers(0, 256, (n, 32), dtype=np.uint8))
+    f[: n // 10] = rng.integers(0, 256, (n // 10, 32), dtype=np.uint8)
+    got = voc.transform_features(m, f, 4)
+    want = ref.transform_features(f, 4)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    assert np.array_equal(got[2].view(np.uint64), want[2].view(np.uint64))
+    # node ids at level L - 4 = 2: the hundred grandchildren of the root
+    assert len(np.unique(got[1])) <= 100 and len(np.unique(got[0])) > n // 2
+    path = str(tmp_path / "voc_k10_L6.txt")
+    voc.saveToTextFile(path, k=k)
+    v2 = orb.ORBVocabulary.loadFromTextFile(path)
+    assert (v2.k, v2.L, v2.size()) == (k, L, 10 ** 6)
+    assert np.array_equal(v2.parent, parent) and np.array_equal(v2.desc[1:], desc[1:]) and np.array_equal(v2.weight[1:], weight[1:])
+    again = v2.transform_features(m, f[:4000], 4)
+    assert all(np.array_equal(a, b[:4000]) for a, b in zip(again, got))

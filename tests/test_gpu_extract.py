@@ -166,6 +166,24 @@ def test_large_batch_frame_groups(orb, orbref, synth, score):
         _assert_same(rkp, rdesc, out[f][0], out[f][1])
 
 
+@pytest.mark.parametrize("w,h,nf,nb", [(1280, 720, 2000, 16), (1920, 1080, 4000, 8)])
+def test_full_size_frames_through_one_chunk(orb, orbref, synth, w, h, nf, nb):
+    """The two larger configurations as batches: 16 frames of 1280x720 / 2000 features and 8 of 1920x1080 / 4000
+    through ONE chunk of the batched entry point (two full groups of eight frames / one), every frame against the
+    oracle."""
+    dev = orb.ORBextractor(nf, 1.2, 8, 1, 20, device=0, max_width=w, max_height=h, max_batch=nb)
+    ref = orbref.RefExtractor(nf, 1.2, 8, 1, 20)
+    imgs = synth.synth_batch(w, h, nb, first_idx=700)
+    out = dev.extract_batch(imgs)
+    assert len(out) == nb
+    total = 0
+    for f in range(nb):
+        rkp, rdesc = ref(imgs[f])
+        _assert_same(rkp, rdesc, out[f][0], out[f][1])
+        total += len(rkp)
+    assert total > nb * nf * 0.9
+
+
 def test_strided_input_and_reuse(orb, orbref, synth):
     """A view with a row stride larger than its width, then a different size on the same handle."""
     dev, ref = _make(orb, orbref, 640, 480, 1000, 8, 20)

@@ -177,6 +177,29 @@ def test_knn2_batched_pairs(orb, orbref, synth, scan):
         assert np.array_equal(idx[p], ridx) and np.array_equal(d1[p], rd1) and np.array_equal(d2[p], rd2)
 
 
+_PAIRS64 = {}
+
+
+@pytest.mark.parametrize("scan", SCANS)
+def test_knn2_64_pairs_of_2000_x_2000_in_one_call(orb, orbref, synth, scan):
+    """The frame-pair configuration at its own size: 64 independent pairs of 2000 x 2000 descriptors (a quarter of
+    the queries planted as near-copies of a train row, a twentieth of the train rows exact duplicates) through ONE
+    call, every pair against the oracle's scan."""
+    P, nq, nt = 64, 2000, 2000
+    if not _PAIRS64:
+        qs, ts = zip(*[synth.synth_descriptors(nq, nt, seed=9000 + p) for p in range(P)])
+        _PAIRS64["q"], _PAIRS64["t"] = np.stack(qs), np.stack(ts)
+        _PAIRS64["ref"] = [orbref.knn2(_PAIRS64["q"][p], _PAIRS64["t"][p]) for p in range(P)]
+    q, t = _PAIRS64["q"], _PAIRS64["t"]
+    m = _matcher(orb, scan)
+    idx, d1, d2 = m.knn2(q, t)
+    for p in range(P):
+        ridx, rd1, rd2 = _PAIRS64["ref"][p]
+        assert np.array_equal(idx[p], ridx) and np.array_equal(d1[p], rd1) and np.array_equal(d2[p], rd2), "pair %d" % p
+    # the planted copies are found: at least a fifth of the queries lie within 40 bits of their best row
+    assert (d1 <= 40).mean() > 0.2
+
+
 @pytest.mark.parametrize("scan", SCANS)
 def test_knn2_chunked_large_train(orb, orbref, synth, scan):
     """Few queries against many rows: the train set is split over workgroups and folded."""
