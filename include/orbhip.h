@@ -152,16 +152,24 @@ int orbhip_knn2_device(orbhip_matcher* m, const uint8_t* d_q, int nq, ptrdiff_t 
  * capture, tight serving loops, harnesses that forbid hipMalloc.  The partial results that the train
  * chunks of one call exchange live in a fixed array in device memory (orbhip_knn2_scratch_bytes()
  * = 16 MiB per GPU, held until the process ends) instead of the handle's growable workspace; this
- * call makes no hipMalloc / hipFree.  A call whose partial results (npairs * chunks * nq * 8 bytes,
- * chunks <= max(1, 8 * CUs / (npairs * ceil(nq / 256)))) exceed the array returns ORBHIP_ECAP and
- * launches nothing.  All matchers of a GPU share that GPU's array: calls that overlap in time on one
- * GPU race (calls on one handle are ordered by its stream; handles are not ordered against each
- * other).  Nothing in the array needs clearing between calls: every entry a call reads it has
- * written first. */
+ * call makes no hipMalloc / hipFree.  A call whose partial results (npairs * chunks * nq * 8 bytes) exceed the
+ * array returns ORBHIP_ECAP and launches nothing.  The chunk count is the launch plan's: with few (query block,
+ * pair) units the train set is cut so that the grid fills the chip (4 workgroups per CU for the matrix-core scan, 16
+ * for the popcount scan, at least 2048 rows per chunk), and a chunk never exceeds the 4,194,272 rows the packed
+ * keys can index, so chunks = max(chip-filling count, ceil(nt / 4194272)); orbhip_knn2_partial_bytes returns the
+ * bytes a shape needs (0 for a single chunk) without launching anything, so a caller can test a shape beforehand.
+ * All matchers of a GPU share that GPU's array.  Calls are ordered against each other on the device, whichever
+ * handle and stream they come from (each waits for the previous user's kernels through a per-device event; neither
+ * step allocates), so matchers of different host threads may call concurrently; the exception is a call made
+ * under stream capture, which takes no part in that ordering.  Nothing in the array needs clearing between
+ * calls: every entry a call reads it has written first. */
 int orbhip_knn2_device_noalloc(orbhip_matcher* m, const uint8_t* d_q, int nq, ptrdiff_t q_pair_stride,
                                const uint8_t* d_t, int nt, ptrdiff_t t_pair_stride, int npairs, int idx_base,
                                int32_t* d_idx, int32_t* d_d1, int32_t* d_d2);
 int orbhip_knn2_scratch_bytes(void);
+/* Bytes of partial results orbhip_knn2_device / _noalloc would use for this shape on this handle (0: one chunk, no
+ * scratch needed; -1: invalid arguments).  Host arithmetic; launches nothing. */
+long long orbhip_knn2_partial_bytes(orbhip_matcher* m, int nq, int nt, int npairs);
 /* Host-pointer convenience form of orbhip_knn2_device (copies in and out; blocking). */
 int orbhip_knn2(orbhip_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int nt, int npairs,
                 int32_t* idx, int32_t* d1, int32_t* d2);

@@ -100,6 +100,8 @@ def lib():
     L.orbhip_knn2_device.argtypes = [vp, vp, i32, pd, vp, i32, pd, i32, i32, vp, vp, vp]
     L.orbhip_knn2_device_noalloc.argtypes = [vp, vp, i32, pd, vp, i32, pd, i32, i32, vp, vp, vp]
     L.orbhip_knn2_scratch_bytes.argtypes = []
+    L.orbhip_knn2_partial_bytes.argtypes = [vp, i32, i32, i32]
+    L.orbhip_knn2_partial_bytes.restype = C.c_longlong
     L.orbhip_knn2.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp, vp]
     L.orbhip_knn2_merge_device.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     L.orbhip_knn2_merge_host.argtypes = [vp, i32, i32, vp, vp, vp]

@@ -99,6 +99,7 @@ struct orbhip_extractor {
     std::vector<hipStream_t> workers;
     std::vector<hipEvent_t> worker_done;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool in_capture = false;  // the stream is being captured into a graph: the timing events are recorded around the replay instead
     // host-buffer batches of 512 frames and more go to the device in pieces on a copy stream of their own
     hipStream_t copy_stream = nullptr;
     std::vector<hipEvent_t> copy_done;
@@ -614,7 +615,7 @@ int orbhip_extract_batch_device(orbhip_extractor* e, const uint8_t* d_imgs, int 
     if ((rc = set_size(e, rows, cols, chunk))) return rc;
     e->prof_chunks = 0;
     (void)hipGetLastError();  // a stale error of an earlier, unrelated call must not be charged to these launches
-    HIPCHK(hipEventRecord(e->ev0, e->stream));
+    if (!e->in_capture) HIPCHK(hipEventRecord(e->ev0, e->stream));
     for (int f0 = 0; f0 < batch; f0 += chunk) {
         const int b = std::min(chunk, batch - f0);
         // sub-batches on the worker streams (single stream while per-stage timing is on, or for tiny chunks)
@@ -640,7 +641,7 @@ int orbhip_extract_batch_device(orbhip_extractor* e, const uint8_t* d_imgs, int 
         }
         e->last_batch = b;
     }
-    HIPCHK(hipEventRecord(e->ev1, e->stream));
+    if (!e->in_capture) HIPCHK(hipEventRecord(e->ev1, e->stream));
     return ORBHIP_OK;
 }
 
@@ -759,8 +760,22 @@ int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int batch, in
                 HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
                 e->copy_done.push_back(ev);
             }
+            // Arenas for the largest piece before the first one is queued: pieces are cut at multiples of eight frames, so
+            // a later piece can be larger than the first, and growing an arena then would free memory that queued
+            // kernels still use (and serialise the overlap this path exists for).
+            auto piece_begin = [&](int k) { return k >= pieces ? b : (int)((long long)b * k / pieces) & ~7; };
+            int largest = 0;
+            for (int k = 0; k < pieces; k++) largest = std::max(largest, piece_begin(k + 1) - piece_begin(k));
+            if ((rc = set_size(e, rows, cols, std::min(largest, e->max_batch)))) return rc;
+            // an error inside the loop leaves copies and kernels in flight that read the staging area or the caller's
+            // frames: drain both streams before handing the error back
+            auto fail = [&](int code) {
+                (void)hipStreamSynchronize(e->copy_stream);
+                (void)hipStreamSynchronize(e->stream);
+                return code;
+            };
             for (int k = 0; k < pieces; k++) {
-                const int s0 = (int)((long long)b * k / pieces) & ~7, s1 = k + 1 == pieces ? b : (int)((long long)b * (k + 1) / pieces) & ~7;
+                const int s0 = piece_begin(k), s1 = piece_begin(k + 1);
                 const uint8_t* src = imgs + (size_t)(f0 + s0) * img_bytes;
                 if (!direct) {
                     // one thread packs about 10 GB/s, a fifth of what the link moves: a piece is packed by a few
@@ -793,14 +808,15 @@ int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int batch, in
                     for (std::thread& th : helpers) th.join();
                     src = stage + (size_t)s0 * img_bytes;
                 }
-                HIPCHK(hipMemcpyAsync(e->d_img.as<uint8_t>() + (size_t)s0 * img_bytes, src, img_bytes * (size_t)(s1 - s0),
-                                      hipMemcpyHostToDevice, e->copy_stream));
-                HIPCHK(hipEventRecord(e->copy_done[k], e->copy_stream));
-                HIPCHK(hipStreamWaitEvent(e->stream, e->copy_done[k], 0));
+                if (hipMemcpyAsync(e->d_img.as<uint8_t>() + (size_t)s0 * img_bytes, src, img_bytes * (size_t)(s1 - s0),
+                                   hipMemcpyHostToDevice, e->copy_stream) != hipSuccess ||
+                    hipEventRecord(e->copy_done[k], e->copy_stream) != hipSuccess ||
+                    hipStreamWaitEvent(e->stream, e->copy_done[k], 0) != hipSuccess)
+                    return fail(orb_fail(ORBHIP_EHIP, "queueing the copy of piece %d failed: %s", k, hipGetErrorString(hipGetLastError())));
                 if ((rc = orbhip_extract_batch_device(e, e->d_img.as<uint8_t>() + (size_t)s0 * img_bytes, s1 - s0, rows, cols, cols,
                                                       (ptrdiff_t)img_bytes, (OrbKeypoint*)(dblk + kp_off) + (size_t)s0 * cap,
                                                       dblk + desc_off + (size_t)32 * cap * s0, cap, (int*)(dblk + n_off) + s0)))
-                    return rc;
+                    return fail(rc);
             }
             HIPCHK(hipMemcpyAsync(dblk, e->d_err.p, sizeof(int), hipMemcpyDeviceToDevice, e->stream));
             HIPCHK(hipMemcpyAsync((void*)hblk, dblk, used, hipMemcpyDeviceToHost, e->stream));
@@ -846,7 +862,9 @@ int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int batch, in
                 hipGraph_t graph = nullptr;
                 bool ok = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
                 if (ok) {
+                    e->in_capture = true;
                     const int qrc = enqueue();
+                    e->in_capture = false;
                     const hipError_t endrc = hipStreamEndCapture(e->stream, &graph);
                     ok = qrc == ORBHIP_OK && endrc == hipSuccess && graph != nullptr && key.generation == g_buffer_generation.load();
                 }
@@ -861,7 +879,11 @@ int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int batch, in
                 }
             }
             if (e->graph_exec) {
+                // the timing events bracket the replay (events recorded inside a capture belong to the graph and
+                // cannot be queried)
+                HIPCHK(hipEventRecord(e->ev0, e->stream));
                 HIPCHK(hipGraphLaunch(e->graph_exec, e->stream));
+                HIPCHK(hipEventRecord(e->ev1, e->stream));
                 e->last_batch = 1;
                 replayed = true;
             }

@@ -137,6 +137,9 @@ static int default_scan_kernel();
 static __device__ __align__(256) unsigned char scratch[KNN_SCRATCH_BYTES];
 #define KNN_SCRATCH_MAX_DEVICES 64
 static void* g_scratch_ptr[KNN_SCRATCH_MAX_DEVICES];
+// One event per device orders the calls that use the device's array against each other, whichever handle (and
+// stream) they come from: a call makes its stream wait for the event, and records it again behind its last kernel.
+static hipEvent_t g_scratch_event[KNN_SCRATCH_MAX_DEVICES];
 static std::mutex g_scratch_mutex;
 
 // Resolves, once per device and with that device current, the address of the device's scratch array.
@@ -149,6 +152,10 @@ static int scratch_for_current_device(int device, void** out) {
         const hipError_t err = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
         if (err != hipSuccess || !ptr)
             return orb_fail(ORBHIP_EHIP, "hipGetSymbolAddress(scratch) failed: %s", hipGetErrorString(err));
+        hipEvent_t ev = nullptr;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
+            return orb_fail(ORBHIP_EHIP, "event creation for the scratch array failed");
+        g_scratch_event[device] = ev;
         g_scratch_ptr[device] = ptr;
     }
     *out = g_scratch_ptr[device];
@@ -351,8 +358,39 @@ int orbhip_knn2_device_noalloc(orbhip_matcher* m, const uint8_t* d_q, int nq, pt
                         "(npairs * chunks * nq * 8 bytes; use orbhip_knn2_device or fewer queries per call)",
                         plan.part_bytes, (unsigned)KNN_SCRATCH_BYTES);
     HIPCHK(hipSetDevice(m->device));
-    return knn2_launch(m, plan, d_q, nq, q_pair_stride, d_t, nt, t_pair_stride, npairs, idx_base, (uint2*)m->d_scratch, d_idx,
-                       d_d1, d_d2);
+    if (plan.nchunks == 1)  // a single chunk writes its results directly: the array is not touched
+        return knn2_launch(m, plan, d_q, nq, q_pair_stride, d_t, nt, t_pair_stride, npairs, idx_base, (uint2*)m->d_scratch, d_idx,
+                           d_d1, d_d2);
+    // Several handles (the reference's three threads each build their own matchers) share the device's one array:
+    // this call's kernels wait for the previous user's, on whatever stream that was, and the next user waits for
+    // these.  Neither call allocates.  Under stream capture the events would tie the captured graph to work outside
+    // it, so a capturing caller gets no cross-handle ordering (replays are ordered by whoever launches the graphs).
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(m->stream, &cap) != hipSuccess) {
+        (void)hipGetLastError();
+        cap = hipStreamCaptureStatusNone;
+    }
+    if (cap != hipStreamCaptureStatusNone)
+        return knn2_launch(m, plan, d_q, nq, q_pair_stride, d_t, nt, t_pair_stride, npairs, idx_base, (uint2*)m->d_scratch, d_idx,
+                           d_d1, d_d2);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);  // wait -> launch -> record is one step as seen by other host threads
+    hipEvent_t ev = g_scratch_event[m->device];
+    HIPCHK(hipStreamWaitEvent(m->stream, ev, 0));
+    const int lrc = knn2_launch(m, plan, d_q, nq, q_pair_stride, d_t, nt, t_pair_stride, npairs, idx_base, (uint2*)m->d_scratch,
+                                d_idx, d_d1, d_d2);
+    HIPCHK(hipEventRecord(ev, m->stream));
+    return lrc;
+}
+
+long long orbhip_knn2_partial_bytes(orbhip_matcher* m, int nq, int nt, int npairs) {
+    if (!m || nq < 0 || nt < 0 || npairs < 0 || npairs > 65535) return -1;
+    if (nq == 0 || npairs == 0) return 0;
+    // the plan depends on the sizes alone (and on the handle's scan kernel); the pointers are only checked for alignment
+    KnnPlan plan;
+    static const int32_t dummy[4] = {0, 0, 0, 0};
+    alignas(16) static const uint8_t aligned[16] = {0};
+    if (knn2_check_and_plan(m, aligned, nq, 0, aligned, nt, 0, npairs, dummy, dummy, dummy, &plan)) return -1;
+    return (long long)plan.part_bytes;
 }
 
 int orbhip_knn2(orbhip_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int nt, int npairs, int32_t* idx, int32_t* d1,

@@ -119,6 +119,8 @@ def test_one_frame_per_call_replays_and_recaptures(orb, orbref, synth):
 
     for i in range(4):
         check(synth.synth_image(640, 480, 40 + i))
+        # the device time of the call just made, replayed or not: some tens of microseconds to a few milliseconds
+        assert 0.01 < dev.last_elapsed_ms() < 20.0, dev.last_elapsed_ms()
     check(synth.synth_image(752, 480, 50))  # new size: new capture
     check(synth.synth_image(640, 480, 51))
     imgs = synth.synth_batch(640, 480, 4, first_idx=60)  # larger arenas: the captured addresses are stale

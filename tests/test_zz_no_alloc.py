@@ -73,3 +73,41 @@ def test_noalloc_rejects_oversized_partials(orb):
                           o[2].data_ptr())
     m.synchronize()
     assert int(o[0].max()) == 0 and int(o[1].max()) == 0 and int(o[2].max()) == 0
+
+
+def test_noalloc_calls_of_two_matchers_are_ordered_on_the_device(orb, synth):
+    """Two handles (two streams) on one GPU call back to back with no host synchronisation in between, several
+    rounds, every call with several train chunks (partial results in the shared array).  Each call waits on the
+    device for the previous user of the array, so every result equals the growable entry point's."""
+    import torch
+    L = orb._lib.lib()
+    ma, mb = orb.ORBmatcher(0.6, True), orb.ORBmatcher(0.6, True)
+    shapes = [(1500, 200000, 31), (700, 90000, 32)]
+    data, want = [], []
+    for m, (nq, nt, seed) in zip((ma, mb), shapes):
+        q, t = synth.synth_descriptors(nq, nt, seed=seed)
+        dq, dt = torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()
+        assert L.orbhip_knn2_partial_bytes(m._h, nq, nt, 1) > 0  # several chunks: the array is used
+        ref = torch.full((3, nq), -7, dtype=torch.int32, device="cuda")
+        m.knn2_device(dq.data_ptr(), nq, nq * 32, dt.data_ptr(), nt, nt * 32, 1, 0, ref[0].data_ptr(), ref[1].data_ptr(), ref[2].data_ptr())
+        m.synchronize()
+        data.append((dq, dt, nq, nt))
+        want.append(ref.cpu().numpy())
+    rounds = 6
+    outs = [[torch.full((3, d[2]), -9, dtype=torch.int32, device="cuda") for _ in range(rounds)] for d in data]
+    torch.cuda.synchronize()
+    for r in range(rounds):
+        for k, m in enumerate((ma, mb)):
+            dq, dt, nq, nt = data[k]
+            o = outs[k][r]
+            m.knn2_device_noalloc(dq.data_ptr(), nq, nq * 32, dt.data_ptr(), nt, nt * 32, 1, 0, o[0].data_ptr(), o[1].data_ptr(),
+                                  o[2].data_ptr())
+    ma.synchronize()
+    mb.synchronize()
+    for k in range(2):
+        for r in range(rounds):
+            assert np.array_equal(outs[k][r].cpu().numpy(), want[k]), "matcher %d, round %d" % (k, r)
+    # the byte count the library reports is what decides ECAP: the rejected shape of the test above needs more than the array
+    assert L.orbhip_knn2_partial_bytes(ma._h, 1000000, 9000000, 1) > L.orbhip_knn2_scratch_bytes()
+    assert L.orbhip_knn2_partial_bytes(ma._h, 1000000, 1024, 1) == 0
+    assert L.orbhip_knn2_partial_bytes(ma._h, -1, 5, 1) == -1
