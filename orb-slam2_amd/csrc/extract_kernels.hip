@@ -7,6 +7,7 @@
 // is compiled with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "extract_kernels.h"
 #include "fast_measure.h"
@@ -837,17 +838,8 @@ struct SlotRec {
     int valid;
 };
 
-__global__ __launch_bounds__(256) void k_slots(const GeomDev* __restrict__ g, const uint32_t* __restrict__ lvl_list,
-                                               int key_words, const int* __restrict__ lvl_count, SlotRec* __restrict__ recs,
-                                               int* __restrict__ n_out) {
-    const int f = blockIdx.y;
-    const int slot = blockIdx.x * 256 + threadIdx.x;
-    if (slot == 0) {
-        int n = 0;
-        for (int l = 0; l < g->nlevels; l++) n += lvl_count[f * g->nlevels + l];
-        n_out[f] = n;
-    }
-    if (slot >= g->nfeatures) return;
+__device__ __forceinline__ SlotRec make_slot_rec(const GeomDev* __restrict__ g, const uint32_t* __restrict__ lvl_list, int key_words,
+                                                 const int* __restrict__ lvl_count, int f, int slot) {
     SlotRec r;
     r.valid = 0;
     r.pix = 0;
@@ -867,7 +859,101 @@ __global__ __launch_bounds__(256) void k_slots(const GeomDev* __restrict__ g, co
         r.kp_size = L.kp_size;
         r.valid = 1 + L.stride;  // non-zero; carries the plane's row stride
     }
-    recs[(long long)f * g->nfeatures + slot] = r;
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_slots(const GeomDev* __restrict__ g, const uint32_t* __restrict__ lvl_list,
+                                               int key_words, const int* __restrict__ lvl_count, SlotRec* __restrict__ recs,
+                                               int* __restrict__ n_out) {
+    const int f = blockIdx.y;
+    const int slot = blockIdx.x * 256 + threadIdx.x;
+    if (slot == 0) {
+        int n = 0;
+        for (int l = 0; l < g->nlevels; l++) n += lvl_count[f * g->nlevels + l];
+        n_out[f] = n;
+    }
+    if (slot >= g->nfeatures) return;
+    recs[(long long)f * g->nfeatures + slot] = make_slot_rec(g, lvl_list, key_words, lvl_count, f, slot);
+}
+
+// The same records in the order the descriptor kernel should WORK in, which is not the output order: the kernel
+// handles eight consecutive records per workgroup, and its time goes into the vector-cache lines the two windows
+// of a keypoint touch (every miss of a window line is a trip to the L2).  Neighbouring keypoints' windows overlap, so
+// the records of a frame are sorted by (level, position along a Z-order curve over a 16 x 16 grid of the level image):
+// a workgroup's eight keypoints then sit next to each other and share lines in the CU's cache.  A record carries its
+// output index, so the result does not depend on the order.  One workgroup per frame, counting sort in LDS
+// (histogram by atomics, exclusive scan, scatter); frames of up to SLOT_SORT_MAX output slots.
+#define SLOT_SORT_THREADS 1024
+#define SLOT_SORT_PER 4
+#define SLOT_SORT_MAX (SLOT_SORT_THREADS * SLOT_SORT_PER)
+#define SLOT_SORT_BINS (ORB_MAX_LEVELS * 256 + 1)  // + one bin behind all others for the empty slots
+
+__device__ __forceinline__ uint32_t morton4(uint32_t x, uint32_t y) {  // 4-bit x, y -> 8-bit interleave
+    x = (x | (x << 2)) & 0x33u;
+    x = (x | (x << 1)) & 0x55u;
+    y = (y | (y << 2)) & 0x33u;
+    y = (y | (y << 1)) & 0x55u;
+    return x | (y << 1);
+}
+
+__global__ __launch_bounds__(SLOT_SORT_THREADS) void k_slots_sorted(const GeomDev* __restrict__ g, const uint32_t* __restrict__ lvl_list,
+                                                                    int key_words, const int* __restrict__ lvl_count,
+                                                                    SlotRec* __restrict__ recs, int* __restrict__ n_out) {
+    __shared__ int hist[SLOT_SORT_BINS];
+    __shared__ int wsum[SLOT_SORT_THREADS / 64];
+    const int f = blockIdx.x, tid = threadIdx.x, nf = g->nfeatures;
+    for (int i = tid; i < SLOT_SORT_BINS; i += SLOT_SORT_THREADS) hist[i] = 0;
+    if (tid == 0) {
+        int n = 0;
+        for (int l = 0; l < g->nlevels; l++) n += lvl_count[f * g->nlevels + l];
+        n_out[f] = n;
+    }
+    __syncthreads();
+    SlotRec r[SLOT_SORT_PER];
+    int bin[SLOT_SORT_PER], rank[SLOT_SORT_PER];
+#pragma unroll
+    for (int k = 0; k < SLOT_SORT_PER; k++) {
+        const int slot = k * SLOT_SORT_THREADS + tid;
+        bin[k] = -1;
+        if (slot < nf) {
+            r[k] = make_slot_rec(g, lvl_list, key_words, lvl_count, f, slot);
+            bin[k] = SLOT_SORT_BINS - 1;
+            if (r[k].valid) {
+                const int level = r[k].level_oi >> 24;
+                const LevelGeom& L = g->lv[level];
+                // the level image cut into 16 x 16 cells (cell sides rounded up, so the last cell index is at most 15)
+                const uint32_t x = r[k].key & 0xfffu, y = (r[k].key >> 12) & 0xfffu;
+                const uint32_t cx = min((x * 16u) / (uint32_t)max(L.w, 1), 15u), cy = min((y * 16u) / (uint32_t)max(L.h, 1), 15u);
+                bin[k] = level * 256 + (int)morton4(cx, cy);
+            }
+            rank[k] = atomicAdd(&hist[bin[k]], 1);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the bins: every thread sums a run of bins, the runs are scanned wave by wave
+    const int per = (SLOT_SORT_BINS + SLOT_SORT_THREADS - 1) / SLOT_SORT_THREADS;
+    const int b0 = min(tid * per, SLOT_SORT_BINS), b1 = min(b0 + per, SLOT_SORT_BINS);
+    int mine = 0;
+    for (int b = b0; b < b1; b++) mine += hist[b];
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if ((tid & 63) >= o) incl += v;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    int off = incl - mine;
+    for (int w = 0; w < (tid >> 6); w++) off += wsum[w];
+    for (int b = b0; b < b1; b++) {
+        const int c = hist[b];
+        hist[b] = off;
+        off += c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SLOT_SORT_PER; k++)
+        if (bin[k] >= 0) recs[(long long)f * nf + hist[bin[k]] + rank[k]] = r[k];
 }
 
 // IC_Angle (src/ORBextractor.cc:124-151) + computeOrbDescriptor (:154-194) + the output record of
@@ -1204,8 +1290,16 @@ void launch_orient_describe(hipStream_t st, const GeomDev& hg, int batch, const 
                             const GeomDev* dg, const uint32_t* lvl_list, int key_words, const int* lvl_count,
                             const uint32_t* otab, float* angles, const int8_t* pattern, void* slot_recs,
                             OrbKeypointDev* kp_out, uint8_t* desc_out, int* n_out, int cap) {
-    hipLaunchKernelGGL(k_slots, dim3((hg.nfeatures + 255) / 256, batch), dim3(256), 0, st, dg, lvl_list, key_words, lvl_count,
-                       (SlotRec*)slot_recs, n_out);
+    static const bool sorted = [] {
+        const char* e = getenv("ORBHIP_SLOT_SORT");  // 0: records in output order (tuning experiments)
+        return !(e && e[0] == '0');
+    }();
+    if (sorted && hg.nfeatures <= SLOT_SORT_MAX)
+        hipLaunchKernelGGL(k_slots_sorted, dim3(batch), dim3(SLOT_SORT_THREADS), 0, st, dg, lvl_list, key_words, lvl_count,
+                           (SlotRec*)slot_recs, n_out);
+    else
+        hipLaunchKernelGGL(k_slots, dim3((hg.nfeatures + 255) / 256, batch), dim3(256), 0, st, dg, lvl_list, key_words, lvl_count,
+                           (SlotRec*)slot_recs, n_out);
     dim3 grid((hg.nfeatures + OD_KPB * OD_ROUNDS - 1) / (OD_KPB * OD_ROUNDS), batch), block(256);
     hipLaunchKernelGGL(k_orient_describe, grid, block, 0, st, pyr, blur, dg, (const SlotRec*)slot_recs, key_words, otab, angles,
                        pattern, kp_out, desc_out, cap);
