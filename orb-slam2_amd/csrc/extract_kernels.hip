@@ -960,30 +960,39 @@ __global__ __launch_bounds__(SLOT_SORT_THREADS) void k_slots_sorted(const GeomDe
 // operator() (:769-777) in one kernel, OD_LPK lanes per keypoint, so that the chain of
 // dependent memory round trips (level counts -> key -> pixels) is paid once per keypoint.
 //
-// Orientation: intensity-centroid moments over the radius-15 disc of the UNBLURRED level image.
-// The 31 disc rows are covered by 31 x 8 (unaligned) dword loads, four pixels each; a host-built
-// table gives, per dword, the byte weights (u + 16 inside the disc, else 0) and the inside mask,
-// so that with two v_dot4_u32_u8
+// Both windows of a keypoint (the 31 disc rows of the UNBLURRED level image, the 37 rows of the BLURRED plane that the
+// rotated pattern can reach) are fetched as 16-byte pieces, three per row from the dword at or before the row's first
+// byte: 10 rows per load instruction of the keypoint's 32 lanes (30 of them loading), 4 + 4 instructions per lane.
+// What a wave-level load costs the texture addresser / vector cache of a CU, measured with tools/ta_probe.hip on
+// cache-resident windows: 11 cycles for dwords in rows of 16 lanes, 22 cycles for dwords that are unaligned or lie in
+// rows of 11 lanes (37 tag lookups instead of 6 to 10), 23 cycles for 63 lanes x 16 bytes - four times the bytes per
+// cycle of the cheapest dword shape, and a fifth of the instructions.
+//
+// Orientation: intensity-centroid moments over the radius-15 disc.  The lanes of pieces 0 and 1 of a row rebuild the
+// row's 8 unaligned dwords (bytes x-15+4q .. x-12+4q) from five aligned ones with v_alignbyte (the fifth comes from the
+// next lane); a host-built table gives, per unaligned dword, the byte weights (u + 16 inside the disc, else 0) and the
+// inside mask, so that with two v_dot4_u32_u8
 //   sum(u * I) = dot4(I, u + 16) - 16 * dot4(I, mask),   sum(v * I) = v * dot4(I, mask).
 // The moments are exact integers whatever the summation order.
 //
-// Descriptor: lane i produces descriptor bytes i*OD_BYTES .. (8 tests each) from the BLURRED plane.  The rotated
-// pattern reaches at most 18 px from the keypoint (largest pattern radius 18.38), so the 37 x 37
-// window around it is copied to LDS with row-contiguous aligned dword loads (37 rows of 11
-// dwords) and the 16 scattered samples of each lane are LDS byte reads; gathering them from
-// global memory instead costs one vector-cache tag lookup per lane and sample.
+// Descriptor: lane i produces descriptor byte i (8 tests) from the BLURRED plane.  The rotated pattern reaches at most
+// 18 px from the keypoint (largest pattern radius 18.38), so the 37 x 37 window around it goes to LDS (37 rows of three
+// 16-byte pieces) and the 16 scattered samples of each lane are LDS byte reads; gathering them from global memory
+// instead costs one vector-cache tag lookup per lane and sample.
 #define DS_REACH 18
 #define DS_ROWS (2 * DS_REACH + 1)
-#define DS_DWORDS 11  // 37 bytes from an arbitrary byte address, as aligned dwords (up to 3 bytes of lead-in)
+#define DS_PIECES 3                 // 16-byte pieces per window row: 48 bytes >= 37 + up to 3 bytes of lead-in
+#define DS_DWORDS (4 * DS_PIECES)   // LDS pitch of a window row in dwords
 // Lanes per keypoint.  Every lane of a keypoint computes the same fastAtan2 / cosf / sinf, so fewer
-// lanes per keypoint mean less redundant arithmetic per wave; 16 keeps the loads of one keypoint
-// row-contiguous (each lane then produces 2 descriptor bytes).
+// lanes per keypoint mean less redundant arithmetic per wave; 32 lanes produce one descriptor byte each.
 #define OD_LPK 32
 #define OD_KPB (256 / OD_LPK)  // keypoints per workgroup and round
 #define OD_ROUNDS 1
 #define OD_BYTES (32 / OD_LPK)  // descriptor bytes per lane
-#define DS_ITERS ((DS_ROWS * DS_DWORDS + OD_LPK - 1) / OD_LPK)
-#define OR_ITERS ((31 * 8 + OD_LPK - 1) / OD_LPK)
+#define OD_ROWS_PER_IT (OD_LPK / DS_PIECES)  // window rows per load instruction of a keypoint's lanes
+#define DS_ITERS ((DS_ROWS + OD_ROWS_PER_IT - 1) / OD_ROWS_PER_IT)
+#define OR_ITERS ((31 + OD_ROWS_PER_IT - 1) / OD_ROWS_PER_IT)
+typedef uint32_t od_u32x4 __attribute__((ext_vector_type(4)));
 
 // Developer instrumentation (-DORBHIP_OD_PHASE_TIMING, never in a shipped build): shader-clock cycles the waves of
 // k_orient_describe spend in each phase, summed; read and reset through orbhip_debug_od_phase.
@@ -1008,7 +1017,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
                                                          const int8_t* __restrict__ pattern,
                                                          OrbKeypointDev* __restrict__ kp_out, uint8_t* __restrict__ desc_out,
                                                          int cap) {
-    __shared__ uint32_t ds_win[OD_KPB][DS_ROWS * DS_DWORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t ds_win[OD_KPB][DS_ROWS * DS_DWORDS];
     // the disc weight table and the test pattern are the same for every keypoint: one copy per
     // workgroup in LDS instead of a trip through the vector cache per keypoint
     __shared__ uint2 s_otab[31 * 8];
@@ -1048,24 +1057,27 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
     const __amdgpu_buffer_rsrc_t rs_pyr = plane_rsrc(pyr + fbase, (int)g->frame_bytes),
                                  rs_blur = plane_rsrc(blur + fbase, (int)g->frame_bytes);
     const uint32_t pixf = (uint32_t)(pix - fbase);
-    uint32_t disc[OR_ITERS];
-    // window rows start at the dword at or before column x - 18 (planes and strides are 4-byte aligned)
-    const int lead = (int)((pixf - DS_REACH) & 3u);
-    const uint32_t ocorner = pixf - (uint32_t)(ORB_HALF_PATCH * stride + ORB_HALF_PATCH);
+    // rows start at the dword at or before their first byte (planes and strides are 4-byte aligned)
+    const int lead = (int)((pixf - DS_REACH) & 3u), olead = (int)((pixf - ORB_HALF_PATCH) & 3u);
+    const uint32_t ocorner = pixf - (uint32_t)(ORB_HALF_PATCH * stride + ORB_HALF_PATCH + olead);
     const uint32_t corner = pixf - (uint32_t)(DS_REACH * stride + DS_REACH + lead);
-    uint32_t wreg[DS_ITERS];
-    if (active) {
+    const int rr = li / DS_PIECES, pc = li - DS_PIECES * rr;  // row within the group of rows of one instruction, piece
+    const bool loader = li < OD_ROWS_PER_IT * DS_PIECES;
+    const uint32_t lane_off = __umul24((uint32_t)rr, (uint32_t)stride) + (uint32_t)(16 * pc);
+    od_u32x4 disc[OR_ITERS], wreg[DS_ITERS];
 #pragma unroll
-        for (int it = 0; it < OR_ITERS; it++) {
-            const int idx = min(it * OD_LPK + li, 31 * 8 - 1);
-            disc[it] = __builtin_amdgcn_raw_buffer_load_b32(rs_pyr, ocorner + __umul24((uint32_t)(idx >> 3), (uint32_t)stride) + (uint32_t)(4 * (idx & 7)), 0, 0);
-        }
+    for (int it = 0; it < OR_ITERS; it++) disc[it] = (od_u32x4)(0u);
 #pragma unroll
-        for (int it = 0; it < DS_ITERS; it++) {
-            const int i = min(it * OD_LPK + li, DS_ROWS * DS_DWORDS - 1);
-            const int r = i / DS_DWORDS, cdw = i - r * DS_DWORDS;
-            wreg[it] = __builtin_amdgcn_raw_buffer_load_b32(rs_blur, corner + __umul24((uint32_t)r, (uint32_t)stride) + (uint32_t)(4 * cdw), 0, 0);
-        }
+    for (int it = 0; it < DS_ITERS; it++) wreg[it] = (od_u32x4)(0u);
+    if (active && loader) {
+#pragma unroll
+        for (int it = 0; it < OR_ITERS; it++)
+            if (it * OD_ROWS_PER_IT + rr < 31)
+                disc[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_pyr, ocorner + lane_off, it * OD_ROWS_PER_IT * stride, 0);
+#pragma unroll
+        for (int it = 0; it < DS_ITERS; it++)
+            if (it * OD_ROWS_PER_IT + rr < DS_ROWS)
+                wreg[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_blur, corner + lane_off, it * OD_ROWS_PER_IT * stride, 0);
     }
     if (threadIdx.x < 31 * 8) s_otab[threadIdx.x] = t_otab;
     s_patf[32 * (threadIdx.x & 7) + (threadIdx.x >> 3)] =
@@ -1078,14 +1090,22 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
     int m10 = 0, m01 = 0;
 #pragma unroll
     for (int it = 0; it < OR_ITERS; it++) {
-        const int idx = it * OD_LPK + li;
-        if (idx < 31 * 8) {
-            const int v = (idx >> 3) - ORB_HALF_PATCH;
-            const uint2 w = s_otab[idx];
-            const int s = (int)__builtin_amdgcn_udot4(disc[it], w.y, 0u, false);
-            const int t = (int)__builtin_amdgcn_udot4(disc[it], w.x, 0u, false);
-            m10 += t - 16 * s;
-            m01 += v * s;
+        const int row = it * OD_ROWS_PER_IT + rr;
+        // the aligned dword after this lane's four: the first of the next piece of the row (every lane shuffles; the
+        // lanes of the last piece read a lane they do not need)
+        const uint32_t d4 = (uint32_t)__shfl_down((int)disc[it].x, 1);
+        if (loader && pc < 2 && row < 31) {
+            const int v = row - ORB_HALF_PATCH;
+            const uint32_t d[5] = {disc[it].x, disc[it].y, disc[it].z, disc[it].w, d4};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t px = __builtin_amdgcn_alignbyte(d[q + 1], d[q], (uint32_t)olead);
+                const uint2 w = s_otab[row * 8 + 4 * pc + q];
+                const int sm = (int)__builtin_amdgcn_udot4(px, w.y, 0u, false);
+                const int tm = (int)__builtin_amdgcn_udot4(px, w.x, 0u, false);
+                m10 += tm - 16 * sm;
+                m01 += v * sm;
+            }
         }
     }
 #pragma unroll
@@ -1100,8 +1120,8 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t* __restri
     uint32_t* win = ds_win[threadIdx.x / OD_LPK];
 #pragma unroll
     for (int it = 0; it < DS_ITERS; it++) {
-        const int i = it * OD_LPK + li;
-        if (i < DS_ROWS * DS_DWORDS) win[i] = wreg[it];
+        const int row = it * OD_ROWS_PER_IT + rr;
+        if (loader && row < DS_ROWS) *(od_u32x4*)(win + row * DS_DWORDS + 4 * pc) = wreg[it];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the window is private to this keypoint's lanes
 
