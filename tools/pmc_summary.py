@@ -14,7 +14,7 @@ import glob
 import json
 import sys
 
-WIDE_LOADS = {"k_fast_cell", "k_resize"}  # kernels whose global loads are 16 B per lane
+WIDE_LOADS = {"k_fast_cell", "k_resize", "k_orient_describe"}  # kernels whose global loads are 16 B per lane
 
 
 def per_kernel(d, counter):
