@@ -23,19 +23,25 @@
 // 32 x 32 one at least six; and the chip's clock falls to ~1.7 GHz under this load, so rates are quoted per second.)
 //
 // A lane holds the results of 16 of a tile's 32 rows (ascending) for query lane % 32, so it keeps the two
-// smallest keys over half of the rows; the two lanes of a query are merged at the end.  A key can only enter the
-// query's two smallest if its distance is below the query's second-best distance so far: one wave vote per tile
-// on the minima of the lanes' results, then one vote per result, skips the keyed folds (which are exact whatever
-// the votes let through).
+// smallest keys over half of the rows; the two lanes of a query are merged at the end.
 //
-// The first tiles of a chunk do not vote.  While a scan is young nearly every tile holds a result that enters some
-// query's two smallest (a query's second-best improves about 2 / j times in tile j, and a wave carries 64 queries), so
-// the votes and scalar branches are paid in every tile and skip nothing.  Those tiles (KMM_SORT_TILES_DEFAULT of
-// them) run a branch-free two-slot sorted insertion on float keys instead, three full-rate instructions per result:
-// the key is d - popcount(q) + row / 2^10, and the row fraction is fed to the tile's first matrix instruction as its
-// accumulator input, so the instruction's result is the key.  The two smallest keys per lane are the same two rows
-// the keyed folds would keep (keys are distinct and order like (distance, row)); they are converted to the integer
-// keys once, where the vote path takes over.
+// Keys are floats while a chunk is scanned: d - popcount(q) + row / 2^15, distinct and ordered like (distance, row)
+// (sums of integers of magnitude <= 256 and a 15-bit fraction are exact in fp32: 24 significant bits, checked
+// through the matrix pipe by tools/mfma_exact_probe.hip).  The two smallest keys of a lane are maintained by a
+// branch-free two-slot sorted insertion: min, max, min per key.
+//
+// The first tiles of a chunk insert every result.  While a scan is young nearly every tile holds a result that
+// enters some query's two smallest (a query's second-best improves about 2 / j times in tile j, and a wave carries
+// 64 queries), so a test would be paid in every tile and skip nothing; there the row fraction rides in the
+// accumulator input of the tile's first matrix instruction and a result IS the key (KMM_SORT_TILES_DEFAULT tiles,
+// three full-rate instructions per result).
+// After that a tile is tested first: a key can only enter the query's two smallest if it is below the query's
+// second-best key so far (over both lanes of the query), so one wave vote on the minima of the lanes' results,
+// then one vote per result, skip the insertions (which are exact whatever the votes let through).
+//
+// The row field of a float key holds 2^15 rows: longer chunks are scanned in epochs of 1024 tiles, at whose ends
+// the float keys become the integer keys (distance << 22 | row) in which the result is reported, and the distance
+// of the query's second-best integer key bounds the threshold of the next epoch.
 #pragma once
 #include <type_traits>
 
@@ -44,9 +50,10 @@
 #define KMM_THR_NONE 0x400  // above every d - popcount(q)
 #define KMM_BIAS 256        // keys carry d - popcount(q) + 256 until the end
 #define KMM_TILE 32         // train rows per tile
-#define KMM_FKEY_BITS 10    // row bits of the float keys of the insertion phase (the fraction of the key)
+#define KMM_FKEY_BITS 15    // row bits of the float keys (the fraction of the key)
 #define KMM_FKEY_SCALE (1 << KMM_FKEY_BITS)
-#define KMM_SORT_TILES_MAX (KMM_FKEY_SCALE / KMM_TILE)  // rows of the insertion phase stay below 2^10
+#define KMM_EPOCH_TILES (KMM_FKEY_SCALE / KMM_TILE)  // tiles whose rows fit the fraction
+#define KMM_SORT_TILES_MAX KMM_EPOCH_TILES           // the always-insert phase stays inside the first epoch
 #define KMM_SORT_TILES_DEFAULT 24
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -78,6 +85,21 @@ __device__ __forceinline__ uint32_t kmm_query_second(uint32_t best, uint32_t bes
     const auto b2 = __builtin_amdgcn_permlane32_swap(best2, best2, false, false);
     return min(max(b[0], b[1]), min(b2[0], b2[1]));
 }
+__device__ __forceinline__ float kmm_query_second_f(float k1, float k2) {
+    const uint32_t u1 = __float_as_uint(k1), u2 = __float_as_uint(k2);
+    const auto b = __builtin_amdgcn_permlane32_swap(u1, u1, false, false);
+    const auto b2 = __builtin_amdgcn_permlane32_swap(u2, u2, false, false);
+    return __builtin_fminf(__builtin_fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1])),
+                           __builtin_fminf(__uint_as_float(b2[0]), __uint_as_float(b2[1])));
+}
+
+// A float key of an epoch that starts at (chunk-relative) row row0 as the integer key distance + KMM_BIAS << 22 | row.
+__device__ __forceinline__ uint32_t kmm_integer_key(float fk, int row0) {
+    if (fk == __builtin_inff()) return KNN_NONE;
+    const float d = __builtin_floorf(fk);  // d - popcount(q); the fraction that is left is the row, exactly
+    const uint32_t row = (uint32_t)((fk - d) * (float)KMM_FKEY_SCALE);
+    return ((uint32_t)((int)d + KMM_BIAS) << KNN_IDX_BITS) + (uint32_t)row0 + row;
+}
 
 __global__ __launch_bounds__(256) void k_knn2_mm(const uint32_t* __restrict__ q, int nq, long long q_pair_words,
                                                   const uint32_t* __restrict__ t, int nt, long long t_pair_words,
@@ -105,12 +127,12 @@ __global__ __launch_bounds__(256) void k_knn2_mm(const uint32_t* __restrict__ q,
     const int j0 = chunk * chunk_rows;
     const int rows = min(nt - j0, chunk_rows);
     const uint32_t* __restrict__ tp = t + (long long)pair * t_pair_words + (long long)j0 * 8 + 4 * h;
-    uint32_t best[2], best2[2];
-    float thr[2];
+    uint32_t best[2], best2[2];  // integer keys of the epochs that are done
+    float cap[2];                // what they allow the threshold of the current epoch to be
 #pragma unroll
     for (int qt = 0; qt < 2; qt++) {
         best[qt] = best2[qt] = KNN_NONE;
-        thr[qt] = (float)KMM_THR_NONE;
+        cap[qt] = (float)KMM_THR_NONE;
     }
 
     struct Row4 {
@@ -125,18 +147,19 @@ __global__ __launch_bounds__(256) void k_knn2_mm(const uint32_t* __restrict__ q,
         v.w[3] = p[3];
         return v;
     };
-    // Float keys of the insertion phase: d - popcount(q) + (chunk-relative row) / 2^10.  The row fraction enters as
-    // the accumulator input of a tile's first matrix instruction, so the instruction's result IS the key: sums of
-    // integers of magnitude <= 256 and a 10-bit fraction are exact in fp32 (19 significant bits).  ckey[i] is the
-    // fraction of result register i for the current tile.
-    float fk1[2] = {__builtin_inff(), __builtin_inff()}, fk2[2] = {__builtin_inff(), __builtin_inff()};
+    // State of the current epoch: the lane's two smallest float keys and the query's threshold, in key units
+    // relative to the epoch's first row.
+    float fk1[2], fk2[2], thr[2];
+    const float tile_step = (float)KMM_TILE / KMM_FKEY_SCALE;
+    // Always-insert phase: ckey[i], the accumulator input of result register i, is the fraction of the register's row
+    // counted from the epoch's first row (it advances by a tile per tile), so a result is the key.
+    // Test phase: accumulator input 0, a result is the integer d - popcount(q); the fraction is added to the few
+    // results that pass the votes: lane_frac (tile base + 4 h rows, one register) plus a constant per result register.
     f32x16 ckey;
-#pragma unroll
-    for (int i = 0; i < 16; i++) ckey[i] = (float)(4 * h + (i & 3) + 8 * (i >> 2)) * (1.f / KMM_FKEY_SCALE);
-    auto tile = [&](const int r0, const Row4& cur, auto tail_tag, auto sort_tag) {
+    auto tile = [&](const int r0, const Row4& cur, const float tbase, auto tail_tag, auto sort_tag) {
         constexpr bool TAIL = decltype(tail_tag)::value;
         constexpr bool SORT = decltype(sort_tag)::value;
-        // acc[qt][reg] = d - popcount(q) for row r0 + (reg & 3) + 8 (reg >> 2) + 4 h
+        // acc[qt][reg] = d - popcount(q) (+ ckey[reg]) for row r0 + (reg & 3) + 8 (reg >> 2) + 4 h
         f32x16 acc[2];
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
@@ -158,7 +181,7 @@ __global__ __launch_bounds__(256) void k_knn2_mm(const uint32_t* __restrict__ q,
             }
         }
         if constexpr (SORT) {
-            // every result goes through a two-slot sorted insertion: three full-rate instructions, no vote, no branch
+            // every result goes through the insertion: three full-rate instructions, no vote, no branch
 #pragma unroll
             for (int i = 0; i < 16; i++) {
 #pragma unroll
@@ -168,77 +191,93 @@ __global__ __launch_bounds__(256) void k_knn2_mm(const uint32_t* __restrict__ q,
                     fk1[qt] = __builtin_fminf(fk1[qt], k);
                 }
             }
-            ckey += (float)KMM_TILE / KMM_FKEY_SCALE;
+            ckey += tile_step;
             return;
         }
-        float below[2];
+        // A key is its result + lane_frac + the constant of its register; key < threshold implies
+        // result < threshold - lane_frac, so the votes on that let through a superset (results whose distance ties
+        // with the threshold's inside this very tile), and the insertion is exact whatever they let through.
+        const float lane_frac = tbase + (float)(4 * h) * (1.f / KMM_FKEY_SCALE);
+        float below[2], thr_rel[2];
 #pragma unroll
         for (int qt = 0; qt < 2; qt++) {
             float m = acc[qt][0];
 #pragma unroll
             for (int i = 1; i < 16; i++) m = fminf(m, acc[qt][i]);
-            below[qt] = m - thr[qt];  // negative: some result of the lane is below its second-best
+            thr_rel[qt] = thr[qt] - lane_frac;  // exact: a multiple of 2^-15 below 2^9
+            below[qt] = m - thr_rel[qt];        // negative: some key of the lane may be below the query's second-best
         }
-        const int rbase = r0 + 4 * h;
-        const uint32_t kbase = ((uint32_t)KMM_BIAS << KNN_IDX_BITS) + (uint32_t)rbase;
 #ifdef KMM_EXP_NOFOLD
-        best[0] ^= (uint32_t)__float_as_int(fminf(below[0], below[1]));  // timing experiment: no vote, no fold
+        fk1[0] += fminf(below[0], below[1]);  // timing experiment: no vote, no insertion
         if (false) {
 #else
         if (__builtin_amdgcn_ballot_w64(fminf(below[0], below[1]) < 0.f) != 0) {
 #endif
+            const int rbase = r0 + 4 * h;
 #pragma unroll
             for (int qt = 0; qt < 2; qt++) {
                 if (__builtin_amdgcn_ballot_w64(below[qt] < 0.f) == 0) continue;
                 unsigned long long vote[16];
 #pragma unroll
-                for (int i = 0; i < 16; i++) vote[i] = __builtin_amdgcn_ballot_w64(acc[qt][i] < thr[qt]);
+                for (int i = 0; i < 16; i++) vote[i] = __builtin_amdgcn_ballot_w64(acc[qt][i] < thr_rel[qt]);
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
                     if (vote[i] == 0) continue;
                     const int ro = (i & 3) + 8 * (i >> 2);
-                    uint32_t key = ((uint32_t)(int)acc[qt][i] << KNN_IDX_BITS) + (kbase + (uint32_t)ro);
-                    if (TAIL && rbase + ro >= rows) key = KNN_NONE;
-                    fold_key(key, best[qt], best2[qt]);
+                    float k = (acc[qt][i] + lane_frac) + (float)ro * (1.f / KMM_FKEY_SCALE);
+                    if (TAIL && rbase + ro >= rows) k = __builtin_inff();
+                    fk2[qt] = __builtin_fminf(fk2[qt], __builtin_fmaxf(fk1[qt], k));
+                    fk1[qt] = __builtin_fminf(fk1[qt], k);
                 }
-                // The threshold is the second-smallest key of the QUERY, i.e. over both lanes that share it: the
-                // other lane's keys are of rows before this tile, so a result that ties with it loses on the row.
-                const uint32_t u2 = kmm_query_second(best[qt], best2[qt]);
-                thr[qt] = u2 == KNN_NONE ? (float)KMM_THR_NONE : (float)((int)(u2 >> KNN_IDX_BITS) - KMM_BIAS);
+                // The threshold is the second-smallest key of the QUERY, i.e. over both lanes that share it
+                thr[qt] = __builtin_fminf(cap[qt], kmm_query_second_f(fk1[qt], fk2[qt]));
             }
         }
     };
     if (rows > 0) {
         const int nfull = rows / KMM_TILE;
-        const int nsort = min(nfull, sort_tiles);
+        const int ntiles = (rows + KMM_TILE - 1) / KMM_TILE;
         Row4 cur = load_row(col);
         int ti = 0;
-        for (; ti < nsort; ti++) {
-            const Row4 nxt = load_row((ti + 1) * KMM_TILE + col);
-            tile(ti * KMM_TILE, cur, std::false_type{}, std::true_type{});
-            cur = nxt;
-        }
-        if (nsort > 0) {
-            // float keys -> the integer keys of the vote phase, and the query's threshold over both of its lanes
 #pragma unroll
-            for (int qt = 0; qt < 2; qt++) {
-                // (key + 256) * 2^10 is an integer below 2^20: biased distance above the row
-                const uint32_t u1 = (uint32_t)((fk1[qt] + (float)KMM_BIAS) * (float)KMM_FKEY_SCALE);
-                const uint32_t u2 = (uint32_t)((fk2[qt] + (float)KMM_BIAS) * (float)KMM_FKEY_SCALE);
-                best[qt] = fk1[qt] == __builtin_inff() ? KNN_NONE
-                                                        : ((u1 >> KMM_FKEY_BITS) << KNN_IDX_BITS) + (u1 & (KMM_FKEY_SCALE - 1));
-                best2[qt] = fk2[qt] == __builtin_inff() ? KNN_NONE
-                                                         : ((u2 >> KMM_FKEY_BITS) << KNN_IDX_BITS) + (u2 & (KMM_FKEY_SCALE - 1));
-                const uint32_t s2 = kmm_query_second(best[qt], best2[qt]);
-                thr[qt] = s2 == KNN_NONE ? (float)KMM_THR_NONE : (float)((int)(s2 >> KNN_IDX_BITS) - KMM_BIAS);
+        for (int qt = 0; qt < 2; qt++) fk1[qt] = fk2[qt] = __builtin_inff();
+        {
+            // the always-insert phase, inside the first epoch
+#pragma unroll
+            for (int i = 0; i < 16; i++) ckey[i] = (float)(4 * h + (i & 3) + 8 * (i >> 2)) * (1.f / KMM_FKEY_SCALE);
+            const int nsort = min(nfull, sort_tiles);
+            for (; ti < nsort; ti++) {
+                const Row4 nxt = load_row((ti + 1) * KMM_TILE + col);
+                tile(ti * KMM_TILE, cur, 0.f, std::false_type{}, std::true_type{});
+                cur = nxt;
             }
         }
-        for (; ti < nfull; ti++) {
-            const Row4 nxt = load_row((ti + 1) * KMM_TILE + col);
-            tile(ti * KMM_TILE, cur, std::false_type{}, std::false_type{});
-            cur = nxt;
+        for (int e0 = 0; e0 < ntiles; e0 += KMM_EPOCH_TILES) {
+            const int e1 = min(ntiles, e0 + KMM_EPOCH_TILES), efull = min(nfull, e1);
+#pragma unroll
+            for (int qt = 0; qt < 2; qt++) thr[qt] = __builtin_fminf(cap[qt], kmm_query_second_f(fk1[qt], fk2[qt]));
+            float tbase = (float)(ti - e0) * tile_step;  // fraction of the tile's first row
+            for (; ti < efull; ti++) {
+                const Row4 nxt = load_row((ti + 1) * KMM_TILE + col);
+                tile(ti * KMM_TILE, cur, tbase, std::false_type{}, std::false_type{});
+                cur = nxt;
+                tbase += tile_step;
+            }
+            if (efull < e1) tile(efull * KMM_TILE, cur, tbase, std::true_type{}, std::false_type{});
+            // the epoch's float keys join the integer keys; the next epoch's keys count rows from its own start, so
+            // all it keeps of this one is a bound: the distance of the query's second-best key (a later row of the
+            // same distance loses to it)
+#pragma unroll
+            for (int qt = 0; qt < 2; qt++) {
+                fold_key(kmm_integer_key(fk1[qt], e0 * KMM_TILE), best[qt], best2[qt]);
+                fold_key(kmm_integer_key(fk2[qt], e0 * KMM_TILE), best[qt], best2[qt]);
+                if (e1 < ntiles) {
+                    const uint32_t u2 = kmm_query_second(best[qt], best2[qt]);
+                    cap[qt] = u2 == KNN_NONE ? (float)KMM_THR_NONE : (float)((int)(u2 >> KNN_IDX_BITS) - KMM_BIAS);
+                    fk1[qt] = fk2[qt] = __builtin_inff();
+                }
+            }
         }
-        if (nfull * KMM_TILE < rows) tile(nfull * KMM_TILE, cur, std::true_type{}, std::false_type{});
     }
 
 #ifdef KMM_EXP_CLOCK

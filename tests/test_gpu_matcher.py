@@ -214,6 +214,50 @@ def test_knn2_chunked_large_train(orb, orbref, synth, scan):
 
 
 @pytest.mark.parametrize("scan", SCANS)
+def test_knn2_one_chunk_longer_than_the_float_keys_row_field(orb, orbref, synth, scan):
+    """So many (query block, pair) units that every workgroup scans the whole train set as ONE chunk, and a train set
+    of 70,000 rows: the matrix-core scan's float keys hold 2^15 rows, so it works through the chunk in three epochs
+    (the last with a partial tile).  Equal rows are planted on both sides of the epoch boundaries, exact copies of
+    queries in every epoch: the first index must win across epochs, and a second-best of an earlier epoch must
+    keep later rows of the same distance out."""
+    import torch
+    P, nq, nt = 1100, 64, 70000
+    rng = np.random.default_rng(77)
+    _, t = synth.synth_descriptors(8, nt, seed=31)
+    q = rng.integers(0, 256, (P, nq, 32), dtype=np.uint8)
+    # pair 0: query 0 equals rows in all three epochs, query 1 only a row of the last epoch, query 2 rows either
+    # side of the first boundary, query 3 a near copy early and an exact copy late
+    t[[100, 40000, 69990]] = q[0, 0]
+    t[69999] = q[0, 1]
+    t[[32767, 32768]] = q[0, 2]
+    near = q[0, 3].copy()
+    near[0] ^= 1
+    t[5] = near
+    t[66000] = q[0, 3]
+    # pair 1: the two best rows of query 0 are equal-distance rows in different epochs
+    a, b = q[1, 0].copy(), q[1, 0].copy()
+    a[3] ^= 0x10
+    b[7] ^= 0x01
+    t[30000], t[50000] = a, b
+    m = _matcher(orb, scan)
+    dq, dt = torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()
+    out = torch.zeros((3, P, nq), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    m.knn2_device(dq.data_ptr(), nq, nq * 32, dt.data_ptr(), nt, 0, P, 0, out[0].data_ptr(), out[1].data_ptr(),
+                  out[2].data_ptr())
+    m.synchronize()
+    o = out.cpu().numpy()
+    for p_ in (0, 1, 2, 547, 1099):
+        ridx, rd1, rd2 = orbref.knn2(q[p_], t)
+        assert np.array_equal(o[0, p_], ridx) and np.array_equal(o[1, p_], rd1) and np.array_equal(o[2, p_], rd2), p_
+    assert o[0, 0, 0] == 100 and o[1, 0, 0] == 0 and o[2, 0, 0] == 0
+    assert o[0, 0, 1] == 69999 and o[1, 0, 1] == 0
+    assert o[0, 0, 2] == 32767 and o[2, 0, 2] == 0
+    assert o[0, 0, 3] == 66000 and o[1, 0, 3] == 0 and o[2, 0, 3] == 1
+    assert o[0, 1, 0] == 30000 and o[1, 1, 0] == 1 and o[2, 1, 0] == 1
+
+
+@pytest.mark.parametrize("scan", SCANS)
 def test_knn2_train_rows_at_4_byte_alignment(orb, orbref, synth, scan):
     """The train set only has to be 4-byte aligned (the matrix kernel reads it in 16-byte pieces all the same)."""
     import torch
