@@ -7,11 +7,13 @@ One "step" is one pass of the extractor (pyramid, cell-grid FAST, selection, ori
 rotated-BRIEF descriptors, keypoint records) over one batch of synthetic frames that is already
 resident in HBM.  The workload is the configuration the headline metric is quoted on: 640x480 frames,
 1000 features per frame (8 levels, scale 1.2), 1024 frames per GPU and step (the rate grows with the
-batch until the short launches of the upper pyramid levels are amortised: 181 k / 210 k / 227 k / 234 k frames/s at
-128 / 256 / 512 / 1024 frames).  With N > 1 (one process
-per GPU, launched by torch.distributed.run) every rank processes its own batch of 1024 frames: frames
-are independent, so the path is sharded by frame batch with no data-path collective (weak scaling);
-the only collectives of the timed region are the timing barrier and a MAX over ranks of the elapsed time.
+batch until the short launches of the upper pyramid levels are amortised; --max-batch shows it: with this
+code 153 k / 209 k / 241 k / 261 k / 273 k frames/s in chunks of 32 / 64 / 128 / 256 / 1024 frames).  With
+N > 1 (one process per GPU: the ranks torch.distributed.run starts, or, when the script is started plainly
+with --gpus N, N copies of itself that it launches before anything touches the GPU) every rank processes its
+own batch of 1024 frames: frames are independent, so the path is sharded by frame batch with no data-path
+collective (weak scaling); the only collectives of the timed region are the timing barrier and a MAX over
+ranks of the elapsed time.  --backend gloo rehearses the N > 1 legs with all ranks on the GPUs that are there.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      the dominant kernel group against HBM bandwidth (durations from HIP events on the
