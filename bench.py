@@ -353,6 +353,67 @@ def launch_ranks(world, argv, grace=30.0):
     return worst if 0 <= worst < 256 else 1
 
 
+def run_dist_legs_isolated(args, dist, rank, local_rank, world):
+    """The multi-rank legs (their own RCCL communicator inside the library, an all-gather that has only ever run with
+    one rank where this was written) run in a child process per rank, a torch.distributed job of its own on a fresh
+    port: whatever happens to it - an exception, an abort inside a collective, a hang - the rank that holds the
+    headline measurement survives and reports it.  Returns the legs (rank 0) or an {"error": ...} record."""
+    port = [free_port() if rank == 0 else None]
+    dist.broadcast_object_list(port, src=0)
+    env = rank_environment(os.environ, rank, world, port[0])
+    env["LOCAL_RANK"] = str(local_rank)
+    child = subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__), "--legs-child", "--backend", args.backend],
+                             env=env, stdout=subprocess.PIPE if rank == 0 else sys.stderr, stderr=sys.stderr)
+    try:
+        outb, _ = child.communicate(timeout=args.legs_timeout)
+    except subprocess.TimeoutExpired:
+        child.kill()
+        child.wait()
+        return {"error": "the multi-rank legs did not finish within %d s" % args.legs_timeout}
+    if rank != 0:
+        return None
+    lines = [l for l in (outb or b"").decode(errors="replace").splitlines() if l.startswith("{")]
+    if child.returncode != 0 or not lines:
+        return {"error": "the multi-rank legs ended with exit code %s" % child.returncode}
+    return json.loads(lines[-1])
+
+
+def legs_child_main(args):
+    """A rank of the job run_dist_legs_isolated starts: the multi-rank legs alone; rank 0 prints them as one JSON line."""
+    rank, local_rank, world = (int(os.environ[k]) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"))
+    hook = os.environ.get("ORBHIP_BENCH_LEGS_CHILD_SELFTEST")
+    if hook:  # tests/test_bench_launcher.py: how the parent copes with a child that answers, aborts or hangs
+        if hook == "abort":
+            os.abort()
+        if hook == "hang":
+            time.sleep(3600)
+        print(json.dumps({"selftest": hook, "rank": rank, "world": world, "port": os.environ.get("MASTER_PORT")}), flush=True)
+        return
+    orb = importlib.import_module("orb-slam2_amd")
+    orb._lib.lib()
+    import torch
+    import torch.distributed as dist
+    dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev)
+    gloo = args.backend == "gloo"
+    STDOUT.divert()
+    if gloo:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if gloo else "cuda:%d" % dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    legs = dist_legs(orb, torch, dist, dev, rank, world, dist.barrier, max_over_ranks, gloo)
+    dist.barrier()
+    if rank == 0:
+        STDOUT.emit(legs)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -373,8 +434,11 @@ def main():
                     help="torch.distributed backend of the N > 1 run.  nccl (RCCL) is the measured configuration; gloo is a "
                          "rehearsal of the multi-rank code on fewer GPUs than ranks (ranks share devices, records travel "
                          "through host memory, the library's own RCCL communicator is left out)")
+    ap.add_argument("--legs-child", action="store_true", help=argparse.SUPPRESS)  # internal: see run_dist_legs_isolated
     args = ap.parse_args()
 
+    if args.legs_child:
+        return legs_child_main(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: this process starts the N ranks itself.  It has not
         # touched the GPU (no HIP call, no torch.cuda, liborbhip.so not loaded) and never does.
@@ -442,7 +506,7 @@ def main():
     frames_total = args.batch * args.steps * world
     value = frames_total / elapsed
 
-    dog = Watchdog(args.legs_timeout, rank)
+    dog = Watchdog(args.legs_timeout + 120, rank)  # the isolated multi-rank legs time out by themselves first
     out = None
     if rank == 0:
         roofline, N_frame = extract_roofline(wl, max(3, min(args.steps, 10)))
@@ -475,7 +539,7 @@ def main():
     if not args.no_extra:
         try:
             if use_dist:
-                legs = dist_legs(orb, torch, dist, dev, rank, world, barrier, max_over_ranks, gloo)
+                legs = run_dist_legs_isolated(args, dist, rank, local_rank, world)
             else:
                 legs = single_gpu_legs(orb, torch, dev, wl)
         except Exception as ex:  # a leg that raises must not lose the headline measurement either

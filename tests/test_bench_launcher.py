@@ -68,3 +68,34 @@ def test_without_a_gpu_every_rank_fails_cleanly():
     assert r.stderr.count("needs a GPU") == 2
     assert "torch.distributed.run" not in r.stderr
     assert r.stdout.strip() == ""
+
+
+class _NoCollectives:
+    """Stands in for torch.distributed in a one-rank call of run_dist_legs_isolated."""
+
+    @staticmethod
+    def broadcast_object_list(objs, src=0):
+        return None
+
+
+def _isolated(monkeypatch, hook, timeout=60):
+    import argparse
+    import bench
+    monkeypatch.setenv("ORBHIP_BENCH_LEGS_CHILD_SELFTEST", hook)
+    args = argparse.Namespace(backend="gloo", legs_timeout=timeout)
+    return bench.run_dist_legs_isolated(args, _NoCollectives, 0, 0, 1)
+
+
+def test_isolated_legs_return_what_the_child_prints(monkeypatch):
+    legs = _isolated(monkeypatch, "answer")
+    assert legs["selftest"] == "answer" and legs["rank"] == 0 and legs["world"] == 1 and int(legs["port"]) > 0
+
+
+def test_isolated_legs_survive_a_child_that_aborts(monkeypatch):
+    legs = _isolated(monkeypatch, "abort")
+    assert "error" in legs and "exit code" in legs["error"]
+
+
+def test_isolated_legs_survive_a_child_that_hangs(monkeypatch):
+    legs = _isolated(monkeypatch, "hang", timeout=3)
+    assert "error" in legs and "did not finish" in legs["error"]
