@@ -151,11 +151,28 @@ __device__ __forceinline__ void resize_rows(const uint8_t* __restrict__ rows, in
     }
 }
 
+// Developer instrumentation (-DORBHIP_RZ_PHASE_TIMING, never in a shipped build): shader-clock cycles the waves of
+// k_resize spend in each phase, summed; read and reset through orbhip_debug_rz_phase.
+#ifdef ORBHIP_RZ_PHASE_TIMING
+__device__ unsigned long long rz_phase[8];
+#define RZ_T0 unsigned long long rzt_ = __builtin_readcyclecounter();
+#define RZ_T(k)                                                                           \
+    {                                                                                     \
+        const unsigned long long now_ = __builtin_readcyclecounter();                     \
+        if (threadIdx.x == 0) atomicAdd(&rz_phase[k], now_ - rzt_);                       \
+        rzt_ = now_;                                                                      \
+    }
+#else
+#define RZ_T0
+#define RZ_T(k)
+#endif
+
 __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, const GeomDev* __restrict__ g, int level,
                                                 const int* __restrict__ xofs, const uint32_t* __restrict__ xab,
                                                 const uint32_t* __restrict__ ysrc, const uint32_t* __restrict__ yab,
                                                 int lds_pitch, int lds_rows) {
     extern __shared__ uint4 rz_lds[];
+    RZ_T0
     const LevelGeom& L = g->lv[level];
     const LevelGeom& P = g->lv[level - 1];
     const int tid = threadIdx.y * 64 + threadIdx.x;
@@ -179,6 +196,7 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, const
     const int pc = (Xmax - X0 + 16) >> 4;  // 16-byte chunks per staged row
     // host sized the LDS for the level's scale; a tile that would not fit reads global memory
     const bool staged = pc * 16 <= lds_pitch && nrows <= lds_rows && pc <= 32;
+    RZ_T(0)
     if (staged) {
         // 32 lanes per source row, 8 rows per sweep of the workgroup, four rows in flight per lane
         const int cj = tid & 31, r0 = tid >> 5;
@@ -198,6 +216,7 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, const
             }
         }
     }
+    RZ_T(1)
     int sx[4], sx1[4], a0[4], a1[4];
     uint32_t keep = 0;  // bytes of the dword that are inside the padded plane
 #pragma unroll
@@ -212,7 +231,9 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, const
         a1[b] = xa >> 16;
     }
     const int yend = min(ybase + RZ_ROWS, L.ph);
+    RZ_T(2)
     __syncthreads();
+    RZ_T(3)
     if (!col_ok || ybase >= yend) return;
     const __amdgpu_buffer_rsrc_t dst = plane_rsrc(frame + L.plane_off, L.stride * L.ph);
     const uint32_t dst_off = (uint32_t)dwx * 4u;
@@ -228,6 +249,7 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, const
         }
         resize_rows((const uint8_t*)rz_lds, lds_pitch, sy_min, sx, sx1, a0, a1, ytab_s, ytab_b, ybase, yend, L.h, dst,
                     dst_off, L.stride, keep);
+        RZ_T(4)
     } else {
         resize_rows(src, P.stride, 0, sx, sx1, a0, a1, ytab_s, ytab_b, ybase, yend, L.h, dst, dst_off, L.stride, keep);
     }
@@ -1204,6 +1226,14 @@ __global__ void k_test_measure(const uint8_t* patches, int* out, int n) {
 }
 
 }  // namespace orbk
+
+#ifdef ORBHIP_RZ_PHASE_TIMING
+extern "C" int orbhip_debug_rz_phase(unsigned long long* out8) {
+    unsigned long long z[8] = {0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(orbk::rz_phase), sizeof(z)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(orbk::rz_phase), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 #ifdef ORBHIP_OD_PHASE_TIMING
 extern "C" int orbhip_debug_od_phase(unsigned long long* out8) {
