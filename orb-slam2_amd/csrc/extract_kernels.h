@@ -35,7 +35,7 @@ void launch_blur(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* py
 void launch_orient_describe(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* pyr, const uint8_t* blur,
                             const GeomDev* dg, const uint32_t* lvl_list, int key_words, const int* lvl_count,
                             const uint32_t* otab, float* angles, const int8_t* pattern, void* slot_recs,
-                            OrbKeypointDev* kp_out, uint8_t* desc_out, int* n_out, int cap);
+                            OrbKeypointDev* kp_out, uint8_t* desc_out, int* n_out, int cap, hipEvent_t blur_done = nullptr);
 // slot_recs: scratch of nfeatures * slot_record_bytes() per frame
 size_t slot_record_bytes();
 // HARRIS_SCORE: Harris responses of the FAST candidates into 64-bit keys, then the selection on those.

@@ -1339,7 +1339,7 @@ void launch_blur(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* py
 void launch_orient_describe(hipStream_t st, const GeomDev& hg, int batch, const uint8_t* pyr, const uint8_t* blur,
                             const GeomDev* dg, const uint32_t* lvl_list, int key_words, const int* lvl_count,
                             const uint32_t* otab, float* angles, const int8_t* pattern, void* slot_recs,
-                            OrbKeypointDev* kp_out, uint8_t* desc_out, int* n_out, int cap) {
+                            OrbKeypointDev* kp_out, uint8_t* desc_out, int* n_out, int cap, hipEvent_t blur_done) {
     static const bool sorted = [] {
         const char* e = getenv("ORBHIP_SLOT_SORT");  // 0: records in output order (tuning experiments)
         return !(e && e[0] == '0');
@@ -1350,6 +1350,8 @@ void launch_orient_describe(hipStream_t st, const GeomDev& hg, int batch, const 
     else
         hipLaunchKernelGGL(k_slots, dim3((hg.nfeatures + 255) / 256, batch), dim3(256), 0, st, dg, lvl_list, key_words, lvl_count,
                            (SlotRec*)slot_recs, n_out);
+    // the blurred plane may come from another stream (blur_done): only the descriptor kernel needs it
+    if (blur_done) (void)hipStreamWaitEvent(st, blur_done, 0);
     dim3 grid((hg.nfeatures + OD_KPB * OD_ROUNDS - 1) / (OD_KPB * OD_ROUNDS), batch), block(256);
     hipLaunchKernelGGL(k_orient_describe, grid, block, 0, st, pyr, blur, dg, (const SlotRec*)slot_recs, key_words, otab, angles,
                        pattern, kp_out, desc_out, cap);

@@ -429,3 +429,26 @@ def test_large_host_batch_runs_in_pieces(orb, synth):
     for (kp0, d0), (kp1, d1), (kp2, d2) in zip(ref, got, got_locked):
         assert len(kp0) > 0 and kp0.tobytes() == kp1.tobytes() == kp2.tobytes()
         assert np.array_equal(d0, d1) and np.array_equal(d0, d2)
+
+
+def test_blur_on_its_own_stream_beside_the_selection(orb, orbref, synth, monkeypatch):
+    """Batches of 64 frames and more run the Gaussian blur on a stream of its own beside the selection kernels (both
+    follow the FAST kernel; the descriptor kernel waits for both).  Same keypoints and descriptors as with the blur in
+    line (ORBHIP_BLUR_STREAM=0 when the handle is created), several calls in a row on one handle (the blurred arena is
+    reused from call to call), and equal to the oracle on a sample of the frames."""
+    w, h, nf, b = 320, 240, 500, 80
+    base = [synth.synth_image(w, h, 1500 + i) for i in range(16)]
+    batches = [np.stack([np.roll(base[(i + 3 * k) % 16], (i // 16) + k, axis=1) for i in range(b)]) for k in range(3)]
+    beside = orb.ORBextractor(nf, 1.2, 8, 1, 20, max_width=w, max_height=h, max_batch=b)
+    monkeypatch.setenv("ORBHIP_BLUR_STREAM", "0")
+    inline = orb.ORBextractor(nf, 1.2, 8, 1, 20, max_width=w, max_height=h, max_batch=b)
+    monkeypatch.delenv("ORBHIP_BLUR_STREAM")
+    for imgs in batches:
+        got, ref = beside.extract_batch(imgs), inline.extract_batch(imgs)
+        assert len(got) == len(ref) == b
+        for (kp0, d0), (kp1, d1) in zip(got, ref):
+            assert len(kp0) > 0 and kp0.tobytes() == kp1.tobytes() and np.array_equal(d0, d1)
+    ext = orbref.RefExtractor(nf, 1.2, 8, 1, 20)
+    for i in (0, 37, 79):
+        rkp, rdesc = ext(batches[-1][i])
+        _assert_same(rkp, rdesc, *got[i])
