@@ -808,6 +808,8 @@ int orbhip_extract_batch(orbhip_extractor* e, const uint8_t* imgs, int batch, in
             // frames: drain both streams before handing the error back
             auto fail = [&](int code) {
                 (void)hipStreamSynchronize(e->copy_stream);
+                for (hipStream_t st : e->workers) (void)hipStreamSynchronize(st);
+                for (hipStream_t st : e->blur_streams) (void)hipStreamSynchronize(st);
                 (void)hipStreamSynchronize(e->stream);
                 return code;
             };
